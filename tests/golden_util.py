@@ -1,0 +1,34 @@
+"""Shared by tools/gen_goldens.py (fixture writer) and the tests (fixture readers): seeded block weights
+and inputs, so fixtures hold only seeds + the reference's outputs, not megabytes of weights."""
+import numpy as np
+
+BLOCK_CASES = {
+    # tag: (kind, args, input shape [N,C,H,W], seed)
+    "res32": ("res", dict(cin=32, cout=32, film=False), (2, 32, 16, 16), 301),
+    "res64_32": ("res", dict(cin=64, cout=32, film=False), (2, 64, 16, 16), 302),
+    "res224_96": ("res", dict(cin=224, cout=96, film=False), (2, 224, 16, 16), 303),   # 7 ch/group
+    "resfilm": ("res", dict(cin=64, cout=64, film=True), (2, 64, 16, 16), 304),
+    "attn96": ("attn", dict(ch=96, new=False), (2, 96, 16, 16), 305),
+    "attn128": ("attn", dict(ch=128, new=False), (2, 128, 8, 8), 306),
+    "attn64new": ("attn", dict(ch=64, new=True), (2, 64, 8, 8), 307),
+    "down": ("down", dict(ch=32), (2, 32, 16, 16), 308),
+    "up": ("up", dict(ch=64), (2, 64, 8, 8), 309),
+}
+EMB_DIM = 128
+
+
+def block_tensors(seed, shapes, x_shape):
+    """Deterministic (weights dict, x, emb) for one block.  `shapes` is an ordered {key: shape}."""
+    rng = np.random.default_rng(seed)
+    w = {}
+    for k, shp in shapes.items():
+        shp = tuple(shp)
+        if len(shp) == 1:
+            is_gamma = k.endswith("weight") and (".0." in k or k.startswith("norm") or "norm." in k) and "emb" not in k
+            v = 0.1 * rng.standard_normal(shp) + (1.0 if is_gamma else 0.0)
+        else:
+            v = rng.standard_normal(shp) / np.sqrt(np.prod(shp[1:]))
+        w[k] = v.astype(np.float32)
+    x = rng.standard_normal(x_shape).astype(np.float32)
+    emb = rng.standard_normal((x_shape[0], EMB_DIM)).astype(np.float32)
+    return w, x, emb
