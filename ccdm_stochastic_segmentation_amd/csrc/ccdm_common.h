@@ -1,0 +1,57 @@
+// Shared device/host helpers for libccdm_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "ccdm_hip.h"
+
+namespace ccdm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+void set_error(const std::string& s);
+int fail(const char* fmt, ...);
+
+#define CCDM_CHECK_LAUNCH(what)                                               \
+    do {                                                                      \
+        hipError_t _e = hipGetLastError();                                    \
+        if (_e != hipSuccess) return ::ccdm::fail("%s: %s", what, hipGetErrorString(_e)); \
+    } while (0)
+
+#define CCDM_REQUIRE(cond, ...)                     \
+    do {                                            \
+        if (!(cond)) return ::ccdm::fail(__VA_ARGS__); \
+    } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- conv launch geometry (shared by the kernel dispatcher, the packer and ccdm_conv_slices) ----
+struct ConvGeo {
+    int TH, TW, waves, MI;   // output tile, waves per block, 32-pixel sub-tiles per wave
+};
+static inline ConvGeo conv_geo(int Hout, int Wout, int stride) {
+    (void)Hout;
+    if (stride == 2) return {8, 8, 2, 1};
+    if (Wout >= 32) return {8, 32, 4, 2};
+    if (Wout >= 16) return {8, 16, 4, 1};
+    return {8, 8, 2, 1};
+}
+// number of 32-wide output-channel tiles one block computes, and the padded tile count
+static inline void conv_ntiles(int Cout, int* ntiles_padded, int* NI) {
+    int raw = cdiv(Cout, 32);
+    if (raw <= 4) { *NI = raw; *ntiles_padded = raw; return; }
+    for (int ni = 4; ni >= 2; --ni)
+        if (raw % ni == 0) { *NI = ni; *ntiles_padded = raw; return; }
+    *NI = 4; *ntiles_padded = cdiv(raw, 4) * 4;
+}
+static inline int conv_cin_pad(int Cin) { return cdiv(Cin, 32) * 32; }
+
+int launch_conv(const ccdm_conv_args& a, hipStream_t s);
+int launch_attention(const float* qkv, float* out, int N, int T, int C, int heads, int order, hipStream_t s);
+int launch_posterior(const ccdm_post_args& a, hipStream_t s);
+
+}  // namespace ccdm

@@ -1,0 +1,318 @@
+// Fused [GroupNorm -> (FiLM) -> SiLU ->] conv KxK [+bias +emb +residual] (+ per-channel output statistics)
+// on NHWC fp32, implicit GEMM on the gfx950 matrix cores.
+//
+//   GEMM view:  M = output pixels (32-pixel sub-tiles of a TH x TW tile), N = output channels (32-wide
+//   tiles), K = taps x input channels, walked in chunks of 32 input channels.  Per chunk the block stages
+//   the (TH-1)*stride+k halo tile into LDS *already normalised and activated* (GroupNorm's affine is folded
+//   to one fma per element from per-channel partial sums the producer left behind), then every tap re-reads
+//   it from LDS: each input element is fetched from HBM once per tile, transformed once, used k*k*Cout times.
+//
+//   A block owns one (sample, slice) pair and loops over that slice's tiles, so it can leave its
+//   per-channel (sum, sum^2) partials for the *next* GroupNorm in a fixed slot — no atomics, fixed order,
+//   run-to-run deterministic.
+//
+// Replaces (reference, /root/reference/ddpm/models/unet_openai/unet.py): ResBlock in/out layers :186-219,
+// :242-262; skip 1x1 :221-228; Downsample :137-146; Upsample :106-116; AttentionBlock norm+qkv / proj_out
+// :291-300; stem :517; head GN-SiLU-conv :701-707.   GroupNorm32 = nn.py:17-19,93-100.
+#include "ccdm_common.h"
+
+namespace ccdm {
+
+static constexpr int CK = 32;          // input channels per K-chunk
+static constexpr int LDS_STRIDE = 33;  // floats per halo pixel (odd: conflict-free column reads)
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+
+struct ConvK {   // kernel-side copy of ccdm_conv_args (+ derived)
+    ccdm_conv_args a;
+    int cin_pad, ntiles, slices, tiles_x, tiles_y;
+};
+
+// ---------------------------------------------------------------------------------------------------
+// GroupNorm affine for sample n:  ab[c] = (scale, shift) such that  y = scale*x + shift
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void compute_gn_affine(const ccdm_conv_args& a, int n, int emb_row, float2* ab) {
+    const int C = a.C0 + a.C1;
+    const int cpg = C / 32;
+    const double cnt = (double)cpg * (double)a.Hin * (double)a.Win;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int c_lo = (c / cpg) * cpg;
+        double sum = 0.0, sq = 0.0;
+        for (int cc = c_lo; cc < c_lo + cpg; ++cc) {
+            const double* st; int ci, Cs, S;
+            if (cc < a.C0) { st = a.stats0; ci = cc; Cs = a.C0; S = a.slices0; }
+            else { st = a.stats1; ci = cc - a.C0; Cs = a.C1; S = a.slices1; }
+            const double* p = st + ((size_t)n * S * Cs + ci) * 2;
+            for (int s = 0; s < S; ++s) {
+                sum += p[(size_t)s * Cs * 2];
+                sq += p[(size_t)s * Cs * 2 + 1];
+            }
+        }
+        const double mean = sum / cnt;
+        double var = sq / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+        const float meanf = (float)mean;
+        float sc = rstd * a.gamma[c];
+        float sh = a.beta[c] - sc * meanf;
+        if (a.film) {   // h = GN(h) * (1 + scale) + shift          unet.py:254-258
+            const float* row = a.emb_table + (size_t)emb_row * a.emb_stride + a.film_off;
+            const float one_plus = 1.0f + row[c];
+            sc = sc * one_plus;
+            sh = sh * one_plus + row[C + c];
+        }
+        ab[c] = make_float2(sc, sh);
+    }
+}
+
+template <int TH, int TW, int WAVES, int MI, int NI>
+__global__ __launch_bounds__(WAVES * 64) void k_conv_f32(const ConvK k) {
+    const ccdm_conv_args& a = k.a;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int C = a.C0 + a.C1;
+    float2* ab = reinterpret_cast<float2*>(smem);                              // [C] (only if stats0)
+    float* halo = reinterpret_cast<float*>(smem + (a.stats0 ? (size_t)C * 8 : 0));
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = blockIdx.x / k.slices, slice = blockIdx.x % k.slices;
+    const int nt0 = blockIdx.y * NI;
+    const int ks = a.ksize, pad = ks >> 1, stride = a.stride;
+    const int HHt = (TH - 1) * stride + ks, HWt = (TW - 1) * stride + ks, HP = HHt * HWt;
+    const int Hc = a.up ? a.Hin * 2 : a.Hin, Wc = a.up ? a.Win * 2 : a.Win;    // conv-input space
+    const int step = a.step_ptr ? *a.step_ptr : 0;
+    const int emb_row = (a.emb_row_of_sample ? a.emb_row_of_sample[n] : 0) + step;
+
+    if (a.stats0) compute_gn_affine(a, n, emb_row, ab);
+
+    // per-lane LDS base of each of this wave's 32-pixel sub-tiles (A operand: row = lane&31, k = lane>>5)
+    int base[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int p = (wave * MI + mi) * 32 + (lane & 31);
+        base[mi] = ((p / TW) * stride * HWt + (p % TW) * stride) * LDS_STRIDE + (lane >> 5);
+    }
+    double s1[NI], s2[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) { s1[ni] = 0.0; s2[ni] = 0.0; }
+
+    const int ntile_sp = k.tiles_x * k.tiles_y;
+    for (int tile = slice; tile < ntile_sp; tile += k.slices) {
+        const int oy0 = (tile / k.tiles_x) * TH, ox0 = (tile % k.tiles_x) * TW;
+        f32x16 acc[MI][NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+
+        for (int c0 = 0; c0 < k.cin_pad; c0 += CK) {
+            __syncthreads();   // previous chunk's reads (and the affine table) are done / visible
+            // ---- stage the halo tile of channels [c0, c0+32), normalised + activated, zero padded ----
+            for (int item = tid; item < HP * (CK / 4); item += WAVES * 64) {
+                const int hp = item >> 3, q = item & 7;
+                const int hy = hp / HWt, hx = hp - hy * HWt;
+                const int iy = oy0 * stride - pad + hy, ix = ox0 * stride - pad + hx;
+                const int c = c0 + 4 * q;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (iy >= 0 && iy < Hc && ix >= 0 && ix < Wc && c < C) {
+                    const int sy = a.up ? (iy >> 1) : iy, sx = a.up ? (ix >> 1) : ix;
+                    const float* src; int cc, Cs;
+                    if (c < a.C0) { src = a.in0; cc = c; Cs = a.C0; }
+                    else { src = a.in1; cc = c - a.C0; Cs = a.C1; }
+                    v = *reinterpret_cast<const float4*>(src + ((size_t)(n * a.Hin + sy) * a.Win + sx) * Cs + cc);
+                    if (a.stats0) {
+                        const float2 t0 = ab[c], t1 = ab[c + 1], t2 = ab[c + 2], t3 = ab[c + 3];
+                        v.x = fmaf(v.x, t0.x, t0.y); v.y = fmaf(v.y, t1.x, t1.y);
+                        v.z = fmaf(v.z, t2.x, t2.y); v.w = fmaf(v.w, t3.x, t3.y);
+                    }
+                    if (a.act == CCDM_ACT_SILU) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+                }
+                float* d = halo + hp * LDS_STRIDE + 4 * q;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+            __syncthreads();
+            // ---- taps x 16 k-steps of v_mfma_f32_32x32x2_f32 ----
+            const float* wc = reinterpret_cast<const float*>(a.w) + ((size_t)(c0 >> 1) * k.ntiles + nt0) * 64 + lane;
+            const size_t wtap = (size_t)(k.cin_pad >> 1) * k.ntiles * 64;
+            for (int tap = 0; tap < ks * ks; ++tap) {
+                const int toff = ((tap / ks) * HWt + (tap % ks)) * LDS_STRIDE;
+                const float* wt = wc + tap * wtap;
+#pragma unroll 4
+                for (int kk = 0; kk < CK / 2; ++kk) {
+                    float av[MI];
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) av[mi] = halo[base[mi] + toff + 2 * kk];
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        const float bv = wt[((size_t)kk * k.ntiles + ni) * 64];
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv, acc[mi][ni], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // ---- epilogue: + bias (+ emb) (+ residual), store NHWC, accumulate output statistics ----
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int co = (nt0 + ni) * 32 + (lane & 31);
+            const bool cv = co < a.Cout;
+            float add = 0.f;
+            if (cv) {
+                add = a.bias ? a.bias[co] : 0.f;
+            }
+            float embv = 0.f;
+            const bool has_emb = a.emb_off >= 0 && cv;
+            if (has_emb) embv = a.emb_table[(size_t)emb_row * a.emb_stride + a.emb_off + co];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int p = (wave * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int oy = oy0 + p / TW, ox = ox0 + p % TW;
+                    if (cv && oy < a.Hout && ox < a.Wout) {
+                        const size_t idx = ((size_t)(n * a.Hout + oy) * a.Wout + ox) * a.Cout + co;
+                        float v = acc[mi][ni][r] + add;
+                        if (has_emb) v += embv;
+                        if (a.resid) v += a.resid[idx];
+                        a.out[idx] = v;
+                        s1[ni] += (double)v;
+                        s2[ni] += (double)v * (double)v;
+                    }
+                }
+            }
+        }
+    }
+
+    if (a.out_stats) {
+        // lanes l and l+32 hold the same channel; then the block's waves; fixed order everywhere
+        __syncthreads();
+        double* red = reinterpret_cast<double*>(halo);     // [WAVES][NI][32][2]
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const double o1 = __shfl_xor(s1[ni], 32), o2 = __shfl_xor(s2[ni], 32);
+            if (lane < 32) {
+                red[((wave * NI + ni) * 32 + lane) * 2 + 0] = s1[ni] + o1;
+                red[((wave * NI + ni) * 32 + lane) * 2 + 1] = s2[ni] + o2;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < NI * 32; i += WAVES * 64) {
+            const int ni = i >> 5, l = i & 31;
+            double t1 = 0.0, t2 = 0.0;
+            for (int w = 0; w < WAVES; ++w) {
+                t1 += red[((w * NI + ni) * 32 + l) * 2 + 0];
+                t2 += red[((w * NI + ni) * 32 + l) * 2 + 1];
+            }
+            const int co = (nt0 + ni) * 32 + l;
+            if (co < a.Cout) {
+                double* o = a.out_stats + (((size_t)n * k.slices + slice) * a.Cout + co) * 2;
+                o[0] = t1; o[1] = t2;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+template <int TH, int TW, int WAVES, int MI>
+static int launch_geo(const ConvK& k, int NI, dim3 grid, size_t lds, hipStream_t s) {
+    dim3 block(WAVES * 64);
+    switch (NI) {
+        case 1: hipLaunchKernelGGL((k_conv_f32<TH, TW, WAVES, MI, 1>), grid, block, lds, s, k); break;
+        case 2: hipLaunchKernelGGL((k_conv_f32<TH, TW, WAVES, MI, 2>), grid, block, lds, s, k); break;
+        case 3: hipLaunchKernelGGL((k_conv_f32<TH, TW, WAVES, MI, 3>), grid, block, lds, s, k); break;
+        case 4: hipLaunchKernelGGL((k_conv_f32<TH, TW, WAVES, MI, 4>), grid, block, lds, s, k); break;
+        default: return fail("conv: bad NI %d", NI);
+    }
+    return 0;
+}
+
+int conv_slices(int Hout, int Wout, int stride) {
+    const ConvGeo g = conv_geo(Hout, Wout, stride);
+    const int tiles = cdiv(Hout, g.TH) * cdiv(Wout, g.TW);
+    return tiles < CCDM_STATS_MAX_SLICES ? tiles : CCDM_STATS_MAX_SLICES;
+}
+
+int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
+    const int C = a.C0 + a.C1;
+    CCDM_REQUIRE(a.in0 && a.out && a.w, "conv: null in0/out/w");
+    CCDM_REQUIRE(a.ksize == 1 || a.ksize == 3, "conv: ksize %d (need 1 or 3)", a.ksize);
+    CCDM_REQUIRE(a.stride == 1 || a.stride == 2, "conv: stride %d", a.stride);
+    CCDM_REQUIRE(a.C0 % 4 == 0 && a.C1 % 4 == 0 && C > 0, "conv: C0=%d C1=%d must be multiples of 4", a.C0, a.C1);
+    CCDM_REQUIRE((a.C1 == 0) == (a.in1 == nullptr), "conv: in1/C1 mismatch");
+    CCDM_REQUIRE(a.prec == CCDM_PREC_F32, "conv: precision %d not built", a.prec);
+    if (a.stats0) {
+        CCDM_REQUIRE(C % 32 == 0, "conv: GroupNorm(32, %d) needs C %% 32 == 0", C);
+        CCDM_REQUIRE(C <= CCDM_MAX_CHANNELS, "conv: %d input channels > CCDM_MAX_CHANNELS", C);
+        CCDM_REQUIRE(a.gamma && a.beta, "conv: GroupNorm without gamma/beta");
+        CCDM_REQUIRE(a.C1 == 0 || a.stats1, "conv: stats1 missing for concatenated input");
+        CCDM_REQUIRE(a.slices0 >= 1 && (a.C1 == 0 || a.slices1 >= 1), "conv: bad stats slices");
+    }
+    CCDM_REQUIRE(!a.film || (a.stats0 && a.emb_table), "conv: FiLM needs GroupNorm and an emb table");
+    const int Hc = a.up ? 2 * a.Hin : a.Hin, Wc = a.up ? 2 * a.Win : a.Win;
+    const int pad = a.ksize / 2;
+    CCDM_REQUIRE(a.Hout == (Hc + 2 * pad - a.ksize) / a.stride + 1 && a.Wout == (Wc + 2 * pad - a.ksize) / a.stride + 1,
+                 "conv: output %dx%d inconsistent with input %dx%d k%d s%d up%d", a.Hout, a.Wout, a.Hin, a.Win, a.ksize, a.stride, a.up);
+
+    ConvK k;
+    k.a = a;
+    k.cin_pad = conv_cin_pad(C);
+    int NI;
+    conv_ntiles(a.Cout, &k.ntiles, &NI);
+    const ConvGeo g = conv_geo(a.Hout, a.Wout, a.stride);
+    k.tiles_x = cdiv(a.Wout, g.TW);
+    k.tiles_y = cdiv(a.Hout, g.TH);
+    k.slices = conv_slices(a.Hout, a.Wout, a.stride);
+    if (a.out_stats) CCDM_REQUIRE(a.out_slices == k.slices, "conv: out_slices %d != %d", a.out_slices, k.slices);
+    const int HP = ((g.TH - 1) * a.stride + a.ksize) * ((g.TW - 1) * a.stride + a.ksize);
+    size_t lds = (size_t)HP * LDS_STRIDE * 4;
+    const size_t red = (size_t)g.waves * NI * 32 * 16;
+    if (lds < red) lds = red;
+    if (a.stats0) lds += (size_t)C * 8;
+    CCDM_REQUIRE(lds <= 160 * 1024, "conv: LDS %zu too large", lds);
+    dim3 grid(a.N * k.slices, k.ntiles / NI);
+    int rc;
+    if (g.TW == 32) rc = launch_geo<8, 32, 4, 2>(k, NI, grid, lds, s);
+    else if (g.TW == 16) rc = launch_geo<8, 16, 4, 1>(k, NI, grid, lds, s);
+    else rc = launch_geo<8, 8, 2, 1>(k, NI, grid, lds, s);
+    if (rc) return rc;
+    CCDM_CHECK_LAUNCH("conv");
+    return 0;
+}
+
+}  // namespace ccdm
+
+extern "C" int ccdm_conv_slices(int Hout, int Wout, int stride, int ksize) {
+    (void)ksize;
+    return ccdm::conv_slices(Hout, Wout, stride);
+}
+
+extern "C" int ccdm_conv2d(const ccdm_conv_args* a, void* stream) {
+    if (!a) return ccdm::fail("ccdm_conv2d: null args");
+    return ccdm::launch_conv(*a, (hipStream_t)stream);
+}
+
+// Packed layout (CCDM_PREC_F32): [tap][cin_pad/2][ntiles][64] floats; lane l of a (tap, k-pair, n-tile)
+// group holds W[cout = nt*32 + (l&31)][cin = 2*kp + (l>>5)][tap] — exactly the B fragment of
+// v_mfma_f32_32x32x2_f32, so a wave fetches it with one coalesced 256-byte load.
+extern "C" size_t ccdm_pack_conv_weight(const float* oihw, int Cout, int Cin, int ksize, int prec, void* out) {
+    if (prec != CCDM_PREC_F32) { ccdm::fail("pack: precision %d not built", prec); return 0; }
+    int ntiles, NI;
+    ccdm::conv_ntiles(Cout, &ntiles, &NI);
+    const int cin_pad = ccdm::conv_cin_pad(Cin), taps = ksize * ksize;
+    const size_t n = (size_t)taps * (cin_pad / 2) * ntiles * 64;
+    if (!out) return n * sizeof(float);
+    float* o = static_cast<float*>(out);
+    for (int tap = 0; tap < taps; ++tap)
+        for (int kp = 0; kp < cin_pad / 2; ++kp)
+            for (int nt = 0; nt < ntiles; ++nt)
+                for (int l = 0; l < 64; ++l) {
+                    const int co = nt * 32 + (l & 31), ci = 2 * kp + (l >> 5);
+                    float v = 0.f;
+                    if (co < Cout && ci < Cin) v = oihw[((size_t)co * Cin + ci) * taps + tap];
+                    o[(((size_t)tap * (cin_pad / 2) + kp) * ntiles + nt) * 64 + l] = v;
+                }
+    return n * sizeof(float);
+}

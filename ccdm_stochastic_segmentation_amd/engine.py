@@ -1,0 +1,361 @@
+"""Host side of the HIP step executor: turns (UNetSpec, state_dict, batch geometry) into device buffers,
+packed weights and the op list of one denoise step, then drives ccdm_engine_run.
+
+torch is used for device memory, streams and H2D copies only; every arithmetic op of the hot path is a
+kernel of libccdm_hip.so (no eager/PyTorch fallback exists — `hip.load()` raises without the library).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import hip
+from .unet_spec import GN_EPS, UNetSpec
+
+
+@dataclass
+class DevTensor:
+    """An NHWC fp32 activation [N,h,w,C] plus the per-channel partial statistics its producer left."""
+    buf: torch.Tensor
+    C: int
+    h: int
+    w: int
+    stats: Optional[torch.Tensor] = None
+    slices: int = 0
+
+    @property
+    def ptr(self) -> int:
+        return self.buf.data_ptr()
+
+    @property
+    def stats_ptr(self) -> int:
+        return self.stats.data_ptr() if self.stats is not None else 0
+
+
+def timestep_embedding_host(timesteps: torch.Tensor, dim: int, max_period: int = 10000) -> torch.Tensor:
+    """Sinusoidal embedding, evaluated with the same torch-CPU ops as the reference
+    (/root/reference/ddpm/models/unet_openai/nn.py:103-121) so the table is bit-identical; see
+    include/ccdm_hip.h (ccdm_time_table) for why this tiny table is not recomputed on the device."""
+    half = dim // 2
+    freqs = torch.exp(-math.log(max_period) * torch.arange(start=0, end=half, dtype=torch.float32) / half)
+    args = timesteps[:, None].float() * freqs[None]
+    emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+    if dim % 2:
+        emb = torch.cat([emb, torch.zeros_like(emb[:, :1])], dim=-1)
+    return emb
+
+
+class SamplerEngine:
+    """One engine per (weights, N, H, W).  Not thread-safe (like the reference's module)."""
+
+    def __init__(self, spec: UNetSpec, state_dict: Dict[str, torch.Tensor], N: int, H: int, W: int,
+                 num_classes: int, img_channels: int, device: torch.device, max_steps: int,
+                 feature_shape: Optional[Tuple[int, int, int]] = None, prec: int = hip.PREC_F32):
+        self.lib = hip.load()
+        if device.type != "cuda":
+            raise hip.CcdmHipError("SamplerEngine needs a HIP device (torch device 'cuda'); there is no CPU path")
+        self.spec, self.N, self.H, self.W = spec, int(N), int(H), int(W)
+        self.K, self.C_img = int(num_classes), int(img_channels)
+        self.device, self.prec = device, prec
+        self.max_steps = max(int(max_steps), self.N, 1)
+        if spec.in_channels != self.K + self.C_img or spec.out_channels != self.K:
+            raise ValueError("spec channels do not match num_classes/img_channels")
+        self._keep: List[torch.Tensor] = []          # every device buffer the op list points into
+        self._sd = {k: v.detach().to("cpu", torch.float32).contiguous() for k, v in state_dict.items()}
+        self.feature_shape = feature_shape
+        self._handle = None
+        with torch.cuda.device(device):
+            # a private non-default stream: HIP graph capture is not allowed on the legacy default stream
+            self.stream = torch.cuda.Stream(device=device)
+            with torch.cuda.stream(self.stream):
+                self._build()
+            self.stream.synchronize()
+
+    # ------------------------------------------------------------------ buffers
+    def _dev(self, shape, dtype=torch.float32, zero=False) -> torch.Tensor:
+        t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
+        self._keep.append(t)
+        return t
+
+    def _upload(self, arr) -> torch.Tensor:
+        t = torch.as_tensor(np.ascontiguousarray(arr)) if not isinstance(arr, torch.Tensor) else arr.contiguous()
+        d = t.to(self.device)
+        self._keep.append(d)
+        return d
+
+    def _act(self, C_: int, h: int, w: int, stats: bool, stride: int = 1) -> DevTensor:
+        buf = self._dev((self.N, h, w, C_))
+        t = DevTensor(buf, C_, h, w)
+        if stats:
+            t.slices = self.lib.ccdm_conv_slices(h, w, stride, 3)
+            t.stats = self._dev((self.N, t.slices, C_, 2), torch.float64)
+        return t
+
+    # ------------------------------------------------------------------ op emission
+    def _conv(self, src: Sequence[DevTensor], wkey: str, cout: int, ksize: int, *, gn: Optional[str] = None,
+              act: int = hip.ACT_NONE, stride: int = 1, up: bool = False, emb_off: int = -1,
+              film_off: int = -1, resid: Optional[DevTensor] = None, stats: bool = True) -> DevTensor:
+        sd = self._sd
+        a, b = src[0], (src[1] if len(src) > 1 else None)
+        cin = a.C + (b.C if b else 0)
+        w = sd[wkey + ".weight"].numpy()
+        assert w.shape[0] == cout and w.shape[1] <= cin, (wkey, w.shape, cin, cout)
+        if w.shape[1] < cin:      # stem: xin is channel-padded to a multiple of 4 with zero channels
+            wp = np.zeros((cout, cin) + tuple(w.shape[2:]), np.float32)
+            wp[:, : w.shape[1]] = w
+            w = wp
+        wdev = self._upload(hip.pack_conv_weight(w, ksize, self.prec))
+        bias = self._upload(sd[wkey + ".bias"].numpy())
+        hin, win = a.h, a.w
+        hc, wc = (2 * hin, 2 * win) if up else (hin, win)
+        pad = ksize // 2
+        hout = (hc + 2 * pad - ksize) // stride + 1
+        wout = (wc + 2 * pad - ksize) // stride + 1
+        out = self._act(cout, hout, wout, stats, stride)
+        args = hip.ConvArgs()
+        args.in0, args.C0 = a.ptr, a.C
+        args.in1, args.C1 = (b.ptr, b.C) if b else (0, 0)
+        if gn is not None:
+            assert a.stats is not None and (b is None or b.stats is not None), f"{wkey}: input has no statistics"
+            args.stats0, args.slices0 = a.stats_ptr, a.slices
+            args.stats1, args.slices1 = (b.stats_ptr, b.slices) if b else (0, 0)
+            args.gamma = self._upload(sd[gn + ".weight"].numpy()).data_ptr()
+            args.beta = self._upload(sd[gn + ".bias"].numpy()).data_ptr()
+        args.eps, args.act = GN_EPS, act
+        args.film, args.film_off = (1, film_off) if film_off >= 0 else (0, 0)
+        args.N, args.Hin, args.Win, args.Hout, args.Wout = self.N, hin, win, hout, wout
+        args.ksize, args.stride, args.up = ksize, stride, int(up)
+        args.w, args.bias, args.Cout, args.prec = wdev.data_ptr(), bias.data_ptr(), cout, self.prec
+        args.emb_table, args.emb_stride, args.emb_off = self.emb_table.data_ptr(), self.E, emb_off
+        args.emb_row_of_sample = self.rowmap.data_ptr()
+        args.step_ptr = 0
+        args.resid = resid.ptr if resid is not None else 0
+        if resid is not None:
+            assert (resid.C, resid.h, resid.w) == (cout, hout, wout), wkey
+        args.out = out.ptr
+        args.out_stats, args.out_slices = out.stats_ptr, out.slices
+        hip.check(self.lib.ccdm_engine_add_conv(self._handle, C.byref(args)), "engine_add_conv " + wkey)
+        self.op_names.append(wkey)
+        return out
+
+    def _res(self, p: str, l, src: Sequence[DevTensor]) -> DevTensor:
+        off = self.emb_offsets[p]
+        if l.film:
+            h = self._conv(src, p + ".in_layers.2", l.cout, 3, gn=p + ".in_layers.0", act=hip.ACT_SILU)
+        else:
+            h = self._conv(src, p + ".in_layers.2", l.cout, 3, gn=p + ".in_layers.0", act=hip.ACT_SILU, emb_off=off)
+        if l.has_skip_conv:
+            skip = self._conv(src, p + ".skip_connection", l.cout, 1, stats=False)
+        else:
+            if len(src) != 1:
+                raise NotImplementedError(f"{p}: identity skip on a concatenated input")
+            skip = src[0]
+        return self._conv([h], p + ".out_layers.3", l.cout, 3, gn=p + ".out_layers.0", act=hip.ACT_SILU,
+                          film_off=off if l.film else -1, resid=skip)
+
+    def _attn(self, p: str, l, x: DevTensor) -> DevTensor:
+        qkv = self._conv([x], p + ".qkv", 3 * l.ch, 1, gn=p + ".norm", act=hip.ACT_NONE, stats=False)
+        a = self._act(l.ch, x.h, x.w, False)
+        hip.check(self.lib.ccdm_engine_add_attention(self._handle, qkv.ptr, a.ptr, self.N, x.h * x.w, l.ch, l.heads,
+                                                     1 if l.new_order else 0), "engine_add_attention")
+        self.op_names.append(p + ".attention")
+        return self._conv([a], p + ".proj_out", l.ch, 1, resid=x)
+
+    def _layers(self, layers, src: Sequence[DevTensor]) -> DevTensor:
+        h: Optional[DevTensor] = None
+        for l in layers:
+            cur = src if h is None else [h]
+            if l.kind == "conv":
+                h = self._conv(cur, l.name, l.cout, 3)
+            elif l.kind == "res":
+                h = self._res(l.name, l, cur)
+            elif l.kind == "attn":
+                h = self._attn(l.name, l, cur[0])
+            elif l.kind == "down":
+                h = self._conv(cur, l.name + ".op", l.cout, 3, stride=2)
+            elif l.kind == "up":
+                h = self._conv(cur, l.name + ".conv", l.cout, 3, up=True)
+            else:  # pragma: no cover
+                raise AssertionError(l.kind)
+        return h
+
+    # ------------------------------------------------------------------ build
+    def _build(self) -> None:
+        spec, sd, N, H, W, K = self.spec, self._sd, self.N, self.H, self.W, self.K
+        lib = self.lib
+        missing = [k for k in spec.param_shapes() if k not in sd]
+        if missing:
+            raise KeyError(f"state_dict is missing {len(missing)} keys, e.g. {missing[:3]}")
+        self.step = self._dev((1,), torch.int32, zero=True)
+        self.rowmap = self._dev((N,), torch.int32, zero=True)
+        self._handle = lib.ccdm_engine_create(self.step.data_ptr())
+        if not self._handle:
+            raise hip.CcdmHipError("engine_create: " + hip.last_error())
+        self.op_names: List[str] = []
+
+        # --- time-conditioning parameters: every ResBlock's emb_layers.1 concatenated -----------------
+        ted, mc = spec.time_embed_dim, spec.model_channels
+        self.emb_offsets: Dict[str, int] = {}
+        ws, bs, off = [], [], 0
+        for name, l in spec.all_layers():
+            if l.kind == "res":
+                self.emb_offsets[name] = off
+                ws.append(sd[name + ".emb_layers.1.weight"].numpy())
+                bs.append(sd[name + ".emb_layers.1.bias"].numpy())
+                off += ws[-1].shape[0]
+        self.E = off
+        self.wcat = self._upload(np.concatenate(ws, 0))
+        self.bcat = self._upload(np.concatenate(bs, 0))
+        self.te = [self._upload(sd[k].numpy()) for k in
+                   ("time_embed.0.weight", "time_embed.0.bias", "time_embed.2.weight", "time_embed.2.bias")]
+        S = self.max_steps
+        self.sinus = self._dev((S, mc))
+        self.emb_table = self._dev((S, self.E))
+        self.step_table = self._dev((S, 4), zero=True)
+
+        # --- boundary buffers -------------------------------------------------------------------------
+        self.Cs = (K + self.C_img + 3) // 4 * 4
+        self.xt = self._dev((N, H * W), torch.uint8, zero=True)
+        self.xin = DevTensor(self._dev((N, H, W, self.Cs), zero=True), self.Cs, H, W)
+        self.feat: Optional[DevTensor] = None
+        if spec.feature_condition_idx:
+            if self.feature_shape is None:
+                raise ValueError("this model concatenates feature conditioning; feature_shape=(C,h,w) is required")
+            fc, fh, fw = self.feature_shape
+            if fc != spec.feature_channels:
+                raise ValueError(f"feature_condition has {fc} channels, model expects {spec.feature_channels}")
+            self.feat = DevTensor(self._dev((N, fh, fw, fc)), fc, fh, fw,
+                                  self._dev((N, 1, fc, 2), torch.float64), 1)
+        self.out_probs = self._dev((N, H, W, K))
+        self.out_onehot = self._dev((N, H, W, K), torch.int64)
+
+        # --- the op list of one denoise step (UNetModel.forward, unet.py:744-808) ----------------------
+        hs: List[DevTensor] = []
+        h = self.xin
+        for i, blk in enumerate(spec.input_blocks):
+            src = [h]
+            if i in spec.feature_condition_idx:
+                if (self.feat.h, self.feat.w) != (h.h, h.w):
+                    raise ValueError(f"feature_condition is {self.feat.h}x{self.feat.w}, U-Net stage is {h.h}x{h.w}")
+                src = [h, self.feat]
+            h = self._layers(blk, src)
+            hs.append(h)
+        h = self._layers(spec.middle_block, [h])
+        for blk in spec.output_blocks:
+            h = self._layers(blk, [h, hs.pop()])
+        self.head = self._conv([h], "out.2", K, 3, gn="out.0", act=hip.ACT_SILU, stats=False)
+        self.n_unet_ops = lib.ccdm_engine_num_ops(self._handle)
+
+        post = hip.PostArgs()
+        post.head, post.softmax = self.head.ptr, int(spec.softmax_output)
+        post.xt, post.N, post.HW, post.K = self.xt.data_ptr(), N, H * W, K
+        post.step_table, post.step_ptr = self.step_table.data_ptr(), 0
+        post.noise, post.noise_step_stride = 0, 0
+        post.philox_seed, post.sample_offset = 0, 0
+        post.xt_next = self.xt.data_ptr()
+        post.xin, post.xin_stride = self.xin.ptr, self.Cs
+        post.out_probs, post.out_onehot, post.posterior_out = self.out_probs.data_ptr(), self.out_onehot.data_ptr(), 0
+        self._post = post
+        hip.check(lib.ccdm_engine_set_epilogue(self._handle, C.byref(post)), "engine_set_epilogue")
+        self._sd = None   # host copies no longer needed
+        self._tables_key = None
+
+    def __del__(self):
+        try:
+            if self._handle:
+                self.lib.ccdm_engine_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ run
+    def _stream(self) -> int:
+        return self.stream.cuda_stream
+
+    def enter(self):
+        """Order the engine's stream after the caller's current stream and make it current."""
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        return torch.cuda.stream(self.stream)
+
+    def leave(self) -> None:
+        """Order the caller's current stream after everything launched on the engine's stream."""
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+
+    def describe_ops(self) -> List[str]:
+        out = []
+        buf = C.create_string_buffer(256)
+        for i in range(self.n_unet_ops):
+            self.lib.ccdm_engine_describe_op(self._handle, i, buf, 256)
+            out.append(f"{i:3d} {self.op_names[i]}: {buf.value.decode()}")
+        return out
+
+    def set_inputs(self, xt_idx: torch.Tensor, cond: torch.Tensor, feat: Optional[torch.Tensor] = None) -> None:
+        """xt_idx uint8 [N,H,W]; cond fp32 [N,C_img,H,W] (reference BCHW); feat fp32 [N,Cf,h,w] or None."""
+        lib, s, N, HW = self.lib, self._stream(), self.N, self.H * self.W
+        assert tuple(xt_idx.shape) == (N, self.H, self.W) and xt_idx.dtype == torch.uint8 and xt_idx.is_cuda
+        assert tuple(cond.shape) == (N, self.C_img, self.H, self.W), (tuple(cond.shape), (N, self.C_img, self.H, self.W))
+        cond = cond.to(self.device, torch.float32).contiguous()
+        self.xt.copy_(xt_idx.reshape(N, HW))
+        hip.check(lib.ccdm_nchw_to_nhwc(cond.data_ptr(), self.xin.ptr, N, self.C_img, HW, self.Cs, self.K, s), "nchw_to_nhwc")
+        hip.check(lib.ccdm_onehot_to_xin(self.xt.data_ptr(), self.xin.ptr, N, HW, self.K, self.Cs, s), "onehot_to_xin")
+        if self.feat is not None:
+            if feat is None:
+                raise ValueError("feature_condition is required by this model")
+            f = self.feat
+            assert tuple(feat.shape) == (N, f.C, f.h, f.w), tuple(feat.shape)
+            feat = feat.to(self.device, torch.float32).contiguous()
+            hip.check(lib.ccdm_nchw_to_nhwc(feat.data_ptr(), f.ptr, N, f.C, f.h * f.w, f.C, 0, s), "nchw_to_nhwc(feat)")
+            hip.check(lib.ccdm_gn_stats(f.ptr, N, f.h * f.w, f.C, 1, f.stats_ptr, s), "gn_stats(feat)")
+        self._cond_keepalive = (cond, feat)
+
+    def set_tables(self, t_rows: Sequence[float], coeffs: Sequence[Tuple[float, float, int]], per_sample: bool = False) -> None:
+        """t_rows[i] = timestep of table row i; coeffs[i] = (alpha_t, cumalpha_tm1, mode).
+        per_sample=True maps sample n to row n (forward_step with a per-sample t)."""
+        S = len(t_rows)
+        if S > self.max_steps:
+            raise ValueError(f"{S} table rows > max_steps {self.max_steps}")
+        key = (tuple(float(t) for t in t_rows), tuple(coeffs), per_sample)
+        if key == self._tables_key:
+            return
+        sin = timestep_embedding_host(torch.tensor(list(t_rows), dtype=torch.float32), self.spec.model_channels)
+        self.sinus[:S].copy_(sin)
+        tab = torch.zeros((S, 4), dtype=torch.float32)
+        for i, (a, c, mode) in enumerate(coeffs):
+            tab[i, 0], tab[i, 1], tab[i, 2] = a, c, float(mode)
+        self.step_table[:S].copy_(tab)
+        self.rowmap.copy_(torch.arange(self.N, dtype=torch.int32) if per_sample else torch.zeros(self.N, dtype=torch.int32))
+        w0, b0, w2, b2 = (t.data_ptr() for t in self.te)
+        hip.check(self.lib.ccdm_time_table(self.sinus.data_ptr(), S, self.spec.model_channels, w0, b0, w2, b2,
+                                           self.wcat.data_ptr(), self.bcat.data_ptr(), self.E, 0,
+                                           self.emb_table.data_ptr(), self._stream()), "time_table")
+        self._tables_key = key
+
+    def run(self, n_steps: int, *, noise: Optional[torch.Tensor] = None, philox_seed: int = 0, sample_offset: int = 0,
+            with_epilogue: bool = True, use_graph: bool = False, first_row: int = 0,
+            posterior_out: Optional[torch.Tensor] = None) -> None:
+        """Launch n_steps denoise steps (asynchronous on the current torch stream)."""
+        npn = self.N * self.H * self.W * self.K
+        if noise is not None:
+            assert noise.is_cuda and noise.dtype == torch.float32 and noise.is_contiguous()
+            assert noise.numel() >= max(first_row + n_steps - 1, 1) * npn, "noise tensor too small"
+            self._noise_keepalive = noise
+        hip.check(self.lib.ccdm_engine_set_run(
+            self._handle, noise.data_ptr() if noise is not None else 0, npn, int(philox_seed) & (2 ** 64 - 1),
+            int(sample_offset), self.out_probs.data_ptr(), self.out_onehot.data_ptr(),
+            posterior_out.data_ptr() if posterior_out is not None else 0), "engine_set_run")
+        hip.check(self.lib.ccdm_engine_run(self._handle, first_row, n_steps, int(with_epilogue), int(use_graph),
+                                           self._stream()), "engine_run")
+
+    # timing taps for bench.py
+    def profile_op(self, op_index: int, capacity: int = 4096) -> None:
+        hip.check(self.lib.ccdm_engine_profile_op(self._handle, op_index, capacity), "engine_profile_op")
+
+    def profile_read(self) -> Tuple[int, float, float, float]:
+        m, lo, hi = C.c_double(), C.c_double(), C.c_double()
+        n = hip.check(self.lib.ccdm_engine_profile_read(self._handle, C.byref(m), C.byref(lo), C.byref(hi)), "profile_read")
+        return n, m.value, lo.value, hi.value

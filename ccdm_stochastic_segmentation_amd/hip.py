@@ -1,0 +1,154 @@
+"""ctypes binding of libccdm_hip.so (the C ABI declared in include/ccdm_hip.h).
+
+There is no CPU fallback: every compute entry point goes to the HIP library, and a missing library is a
+hard error (``load()`` raises).  Importing this module does not load anything, so host-only logic
+(spec, schedules, packing through the library's host functions) works on a box without a GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "libccdm_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+SOURCES = ["ccdm_conv.hip", "ccdm_misc.hip", "ccdm_sampler.hip", "ccdm_engine.hip"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+
+ACT_NONE, ACT_SILU = 0, 1
+PREC_F32, PREC_F16X3 = 0, 1
+STEP_SAMPLE, STEP_LAST_CONFIDENCE, STEP_LAST_MAJORITY, STEP_LAST_KEEP, STEP_SOFTMAX_ONLY = 0, 1, 2, 3, 4
+STATS_MAX_SLICES = 16
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [
+        ("in0", C.c_void_p), ("in1", C.c_void_p), ("C0", C.c_int32), ("C1", C.c_int32),
+        ("stats0", C.c_void_p), ("stats1", C.c_void_p), ("slices0", C.c_int32), ("slices1", C.c_int32),
+        ("gamma", C.c_void_p), ("beta", C.c_void_p),
+        ("eps", C.c_float), ("act", C.c_int32),
+        ("film", C.c_int32), ("film_off", C.c_int32),
+        ("N", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32), ("Hout", C.c_int32), ("Wout", C.c_int32),
+        ("ksize", C.c_int32), ("stride", C.c_int32), ("up", C.c_int32),
+        ("w", C.c_void_p), ("bias", C.c_void_p), ("Cout", C.c_int32), ("prec", C.c_int32),
+        ("emb_table", C.c_void_p), ("emb_stride", C.c_int32), ("emb_off", C.c_int32),
+        ("emb_row_of_sample", C.c_void_p),
+        ("step_ptr", C.c_void_p),
+        ("resid", C.c_void_p),
+        ("out", C.c_void_p),
+        ("out_stats", C.c_void_p), ("out_slices", C.c_int32),
+    ]
+
+
+class PostArgs(C.Structure):
+    _fields_ = [
+        ("head", C.c_void_p), ("softmax", C.c_int32),
+        ("xt", C.c_void_p),
+        ("N", C.c_int32), ("HW", C.c_int32), ("K", C.c_int32),
+        ("step_table", C.c_void_p), ("step_ptr", C.c_void_p),
+        ("noise", C.c_void_p), ("noise_step_stride", C.c_int64),
+        ("philox_seed", C.c_uint64), ("sample_offset", C.c_uint32),
+        ("xt_next", C.c_void_p),
+        ("xin", C.c_void_p), ("xin_stride", C.c_int32),
+        ("out_probs", C.c_void_p),
+        ("out_onehot", C.c_void_p),
+        ("posterior_out", C.c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/ccdm_hip.h declares
+SIGNATURES = {
+    "ccdm_version": (C.c_int, []),
+    "ccdm_last_error_string": (C.c_char_p, []),
+    "ccdm_gn_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "ccdm_conv_slices": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ccdm_conv2d": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
+    "ccdm_pack_conv_weight": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ccdm_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ccdm_time_table": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ccdm_posterior_sample": (C.c_int, [C.POINTER(PostArgs), C.c_void_p]),
+    "ccdm_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ccdm_onehot_to_xin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ccdm_engine_create": (C.c_void_p, [C.c_void_p]),
+    "ccdm_engine_destroy": (None, [C.c_void_p]),
+    "ccdm_engine_add_conv": (C.c_int, [C.c_void_p, C.POINTER(ConvArgs)]),
+    "ccdm_engine_add_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ccdm_engine_set_epilogue": (C.c_int, [C.c_void_p, C.POINTER(PostArgs)]),
+    "ccdm_engine_num_ops": (C.c_int, [C.c_void_p]),
+    "ccdm_engine_set_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ccdm_engine_run": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ccdm_engine_profile_op": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "ccdm_engine_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "ccdm_engine_describe_op": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class CcdmHipError(RuntimeError):
+    pass
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile libccdm_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, "ccdm_common.h"), os.path.join(ROOT, "include", "ccdm_hip.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    cmd = ["hipcc", *HIPCC_FLAGS, "-I" + os.path.join(ROOT, "include"), *srcs, "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise CcdmHipError("hipcc failed:\n" + r.stdout + r.stderr)
+    return LIB_PATH
+
+
+def load() -> C.CDLL:
+    """Load the HIP library; raises (never falls back) if it is missing or lacks a declared symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CcdmHipError(
+            f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'`.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise CcdmHipError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().ccdm_last_error_string().decode("utf-8", "replace")
+
+
+def check(rc: int, what: str = "") -> int:
+    if rc is None or rc < 0:
+        raise CcdmHipError(f"{what}: {last_error()}")
+    return rc
+
+
+def pack_conv_weight(w, ksize: int, prec: int = PREC_F32):
+    """OIHW / OIK numpy fp32 -> packed numpy uint8 buffer (host-side, no GPU needed)."""
+    import numpy as np
+    lib = load()
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    cout, cin = int(w.shape[0]), int(w.shape[1])
+    assert w.size == cout * cin * ksize * ksize, (w.shape, ksize)
+    nbytes = lib.ccdm_pack_conv_weight(None, cout, cin, ksize, prec, None)
+    if nbytes == 0:
+        raise CcdmHipError("pack_conv_weight: " + last_error())
+    out = np.empty(nbytes, dtype=np.uint8)
+    lib.ccdm_pack_conv_weight(w.ctypes.data, cout, cin, ksize, prec, out.ctypes.data)
+    return out

@@ -1,0 +1,336 @@
+"""Drop-in host interface of the sampler: same names, arguments and error behaviour as the reference's
+``ddpm.models`` package for the hot path, backed by the HIP engine.
+
+    build_model(...)                         /root/reference/ddpm/models/builder.py:14-51
+    DenoisingModel.forward(x, condition, feature_condition=None, t=None, label_ref_logits=None, validation=False)
+                                             /root/reference/ddpm/models/diffusion_denoising.py:144-159
+    DiffusionModel (schedule buffers)        /root/reference/ddpm/models/diffusion_denoising.py:42-70
+    UNetModel (parameter container with the reference's state_dict key layout)
+    OneHotCategoricalBCHW                    /root/reference/ddpm/models/one_hot_categorical.py:10-54
+
+Inference only: there is no autograd through the HIP kernels.
+"""
+from __future__ import annotations
+
+import logging
+import math
+from typing import Any, Dict, List, Optional, Tuple, Union, cast
+
+import numpy as np
+import torch
+from torch import Tensor, nn
+
+from . import hip
+from .engine import SamplerEngine
+from .unet_spec import UNetSpec, make_unet_spec
+
+LOGGER = logging.getLogger(__name__)
+
+__all__ = ["build_model", "DiffusionModel", "DenoisingModel", "UNetModel", "OneHotCategoricalBCHW",
+           "linear_schedule", "cosine_schedule", "step_values"]
+
+
+# --------------------------------------------------------------------------------------------------
+# schedules (host, once per model) — same expressions, same dtypes as the reference so the three
+# buffers are bit-identical (diffusion_denoising.py:18-39)
+# --------------------------------------------------------------------------------------------------
+def linear_schedule(time_steps: int, start=1e-2, end=0.2) -> Tuple[Tensor, Tensor, Tensor]:
+    betas = torch.linspace(start, end, time_steps)
+    alphas = 1 - betas
+    return betas, alphas, torch.cumprod(alphas, dim=0)
+
+
+def cosine_schedule(time_steps: int, s: float = 8e-3) -> Tuple[Tensor, Tensor, Tensor]:
+    s = 0.008                                     # the reference ignores the argument (:27)
+    t = torch.arange(0, time_steps)
+    cumalphas = torch.cos(((t / time_steps + s) / (1 + s)) * (math.pi / 2)) ** 2
+
+    def f(u):
+        return math.cos((u + s) / (1.0 + s) * math.pi / 2) ** 2
+
+    betas = torch.tensor([min(1 - f((i + 1) / time_steps) / f(i / time_steps), 0.999) for i in range(time_steps)])
+    return betas, 1 - betas, cumalphas
+
+
+def step_values(time_steps: int, init_t: Optional[int]) -> List[int]:
+    """Step list of forward_denoising (:178-187): full range, a shortened range, or (init_t > 10000) a
+    strided walk of K = init_t % 10000 steps from T to 1 (python round = half-to-even)."""
+    if init_t is None:
+        init_t = time_steps
+    if init_t > 10000:
+        k = init_t % 10000
+        assert 0 < k <= time_steps
+        if k == time_steps:
+            return list(range(k, 0, -1))
+        vals = [round(v) for v in np.linspace(time_steps, 1, k)]
+        LOGGER.warning(f"Override default {time_steps} time steps with {len(vals)}.")
+        return vals
+    return list(range(init_t, 0, -1))
+
+
+class OneHotCategoricalBCHW:
+    """Categorical over dim=1 of a BCHW tensor, sampled as torch.multinomial does: argmax_k p_k / E_k with
+    E ~ Exp(1) drawn as one [B*H*W, K] block from the generator of the tensor's device.  Host-side helper
+    for callers (x_T is drawn with it on the CPU, evaluate_lidc_uncertainty.py:100); the per-step draws
+    inside the loop run in the HIP epilogue."""
+
+    def __init__(self, probs: Optional[Tensor] = None, logits: Optional[Tensor] = None, validate_args=None):
+        if (probs is None) == (logits is None):
+            raise ValueError("Either `probs` or `logits` must be specified, but not both.")
+        if probs is not None and probs.ndim < 2:
+            raise ValueError("`probs.ndim` should be at least 2")
+        if logits is not None and logits.ndim < 2:
+            raise ValueError("`logits.ndim` should be at least 2")
+        if probs is not None:
+            p = self.channels_last(probs)
+            self.probs = p / p.sum(-1, keepdim=True)
+        else:
+            lg = self.channels_last(logits)
+            self.probs = torch.softmax(lg - lg.logsumexp(dim=-1, keepdim=True), dim=-1)
+
+    @staticmethod
+    def channels_last(arr: Tensor) -> Tensor:
+        return arr.permute((0,) + tuple(range(2, arr.ndim)) + (1,))
+
+    @staticmethod
+    def channels_second(arr: Tensor) -> Tensor:
+        return arr.permute((0, arr.ndim - 1) + tuple(range(1, arr.ndim - 1)))
+
+    def sample(self, sample_shape=torch.Size(), generator: Optional[torch.Generator] = None) -> Tensor:
+        if len(sample_shape) != 0:
+            raise NotImplementedError("sample_shape other than () is not used on this path")
+        k = self.probs.shape[-1]
+        p2d = self.probs.reshape(-1, k)
+        q = torch.empty_like(p2d).exponential_(1, generator=generator)
+        idx = torch.argmax(p2d / q, dim=-1)
+        res = torch.nn.functional.one_hot(idx, k).to(self.probs.dtype).reshape(self.probs.shape)
+        return self.channels_second(res)
+
+    def max_prob_sample(self) -> Tensor:
+        k = self.probs.shape[-1]
+        return self.channels_second(torch.nn.functional.one_hot(self.probs.argmax(dim=-1), k))
+
+    def prob_sample(self) -> Tensor:
+        return self.channels_second(self.probs)
+
+
+class DiffusionModel(nn.Module):
+    betas: Tensor
+    alphas: Tensor
+    cumalphas: Tensor
+
+    def __init__(self, schedule: str, time_steps: int, num_classes: int, schedule_params=None):
+        super().__init__()
+        fn = {"linear": linear_schedule, "cosine": cosine_schedule}[schedule]
+        betas, alphas, cumalphas = fn(time_steps, **schedule_params) if schedule_params is not None else fn(time_steps)
+        self.register_buffer("betas", betas)
+        self.register_buffer("alphas", alphas)
+        self.register_buffer("cumalphas", cumalphas)
+        self.num_classes = num_classes
+
+    @property
+    def time_steps(self) -> int:
+        return len(self.betas)
+
+    def posterior_coeffs(self, t: int) -> Tuple[float, float]:
+        """(alpha_t, cumalpha_{t-1}) as theta_post_prob uses them; t == 1 -> (0, 1) (:112-113)."""
+        i = t - 1
+        if i == 0:
+            return 0.0, 1.0
+        return float(self.alphas[i]), float(self.cumalphas[i - 1])
+
+
+class UNetModel(nn.Module):
+    """Parameter container with the reference network's exact state_dict layout (398 tensors for the LIDC
+    config), so `load_state_dict(strict=True)` and ignite's `load_objects` work unchanged.  It has no
+    torch forward: the forward pass is the HIP op list built by SamplerEngine from these parameters."""
+
+    def __init__(self, spec: UNetSpec):
+        super().__init__()
+        self.spec = spec
+        self.in_channels, self.model_channels, self.out_channels = spec.in_channels, spec.model_channels, spec.out_channels
+        self._version_seen = 0
+        self._weights_version = 0
+
+        def container_for(path: List[str]) -> nn.Module:
+            mod: nn.Module = self
+            for part in path:
+                if not hasattr(mod, part):
+                    mod.add_module(part, nn.Module())
+                mod = getattr(mod, part)
+            return mod
+
+        for key, shape in spec.param_shapes().items():
+            *path, leaf = key.split(".")
+            container_for(path).register_parameter(leaf, nn.Parameter(torch.zeros(shape), requires_grad=False))
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.mark_weights_changed())
+
+    def mark_weights_changed(self) -> None:
+        self._weights_version += 1
+
+    def _apply(self, fn, *a, **k):   # .to()/.cuda(): parameters are re-created
+        r = super()._apply(fn, *a, **k)
+        self._weights_version += 1
+        return r
+
+    def forward(self, *args, **kwargs):
+        raise RuntimeError("UNetModel has no eager forward; call it through DenoisingModel (HIP engine)")
+
+
+class DenoisingModel(nn.Module):
+    """The sampler.  `rng` selects where the Exp(1) noise of the categorical draws comes from:
+    "torch_cpu" (default) — drawn on the host from torch's global CPU generator in exactly the order the
+      reference's CPU path consumes it (parity mode; the host RNG is the bottleneck);
+    "philox" — Philox4x32-10 inside the epilogue kernel (throughput mode; statistically identical)."""
+
+    def __init__(self, diffusion: DiffusionModel, unet: UNetModel, dataset_file: str, step_T_sample: str = "majority"):
+        super().__init__()
+        self.diffusion = diffusion
+        self.unet = unet
+        self.dataset_file = dataset_file
+        self.step_T_sample = step_T_sample
+        self.rng = "torch_cpu"
+        self.philox_seed = 0
+        self.sample_offset = 0          # global index of sample 0 when the batch is sharded over ranks
+        self.noise_slice: Optional[Tuple[int, int]] = None   # (global_batch, first_sample) for torch_cpu sharding
+        self.use_graph = False
+        self.prec = hip.PREC_F32
+        self._engines: Dict[Any, Tuple[int, SamplerEngine]] = {}
+
+    @property
+    def time_steps(self) -> int:
+        return self.diffusion.time_steps
+
+    # ------------------------------------------------------------------ reference API
+    def forward(self, x: Tensor, condition: Tensor, feature_condition: Tensor = None, t: Optional[Tensor] = None,
+                label_ref_logits: Optional[Tensor] = None, validation: bool = False) -> Union[Tensor, dict]:
+        if self.training:
+            if not isinstance(t, Tensor):
+                raise ValueError("'t' needs to be a Tensor at training time")
+            if not isinstance(x, Tensor):
+                raise ValueError("'x' needs to be a Tensor at training time")
+            return self.forward_step(x, condition, feature_condition, t)
+        if validation:
+            return self.forward_step(x, condition, feature_condition, t)
+        if t is None:
+            return self.forward_denoising(x, condition, feature_condition, label_ref_logits=label_ref_logits)
+        return self.forward_denoising(x, condition, feature_condition, cast(int, t.item()), label_ref_logits)
+
+    # ------------------------------------------------------------------ engine plumbing
+    def _engine(self, x: Tensor, condition: Tensor, feature_condition: Optional[Tensor]) -> SamplerEngine:
+        N, K, H, W = x.shape
+        fshape = tuple(feature_condition.shape[1:]) if feature_condition is not None else None
+        if not self.unet.spec.feature_condition_idx:
+            fshape = None
+        dev = next(self.unet.parameters()).device
+        key = (N, H, W, int(condition.shape[1]), fshape, str(dev), self.prec)
+        hit = self._engines.get(key)
+        if hit is not None and hit[0] == self.unet._weights_version:
+            return hit[1]
+        eng = SamplerEngine(self.unet.spec, self.unet.state_dict(), N, H, W, K, int(condition.shape[1]), dev,
+                            max_steps=self.time_steps, feature_shape=fshape, prec=self.prec)
+        self._engines = {k: v for k, v in self._engines.items() if v[0] == self.unet._weights_version}
+        self._engines[key] = (self.unet._weights_version, eng)
+        return eng
+
+    @staticmethod
+    def _to_index(x: Tensor, device) -> Tensor:
+        return x.argmax(dim=1).to(device=device, dtype=torch.uint8).contiguous()
+
+    def forward_step(self, x: Tensor, condition: Tensor, feature_condition: Tensor, t: Tensor) -> dict:
+        """One U-Net evaluation at per-sample timesteps `t` (diffusion_denoising.py:161-162 -> unet.py:744-808).
+        `x` must be one-hot (it is everywhere on this path)."""
+        if self.unet.spec.ce_head:
+            raise NotImplementedError("ce_head logits are not produced by the HIP path")
+        eng = self._engine(x, condition, feature_condition)
+        N = x.shape[0]
+        tt = t.detach().float().reshape(-1).cpu()
+        if tt.numel() == 1:
+            tt = tt.expand(N)
+        with eng.enter():
+            eng.set_inputs(self._to_index(x, eng.device), condition.to(eng.device), feature_condition)
+            eng.set_tables([float(v) for v in tt], [(0.0, 1.0, hip.STEP_SOFTMAX_ONLY)] * N, per_sample=True)
+            eng.run(1, with_epilogue=True, use_graph=False)
+            out = eng.out_probs.clone().permute(0, 3, 1, 2)
+        eng.leave()
+        return {"diffusion_out": out, "logits": None}
+
+    def forward_denoising(self, x: Optional[Tensor], condition: Tensor, feature_condition: Tensor,
+                          init_t: Optional[int] = None, label_ref_logits: Optional[Tensor] = None) -> dict:
+        if label_ref_logits is not None:
+            # the reference's guidance branch reads attributes that do not exist (guidance_scale_weights,
+            # diffusion_denoising.py:172-174): it raises AttributeError there too.
+            raise AttributeError("'DenoisingModel' object has no attribute 'guidance_scale_weights'")
+        T = self.time_steps
+        t_values = step_values(T, init_t)
+        eng = self._engine(x, condition, feature_condition)
+        N, K, H, W = x.shape
+        S = len(t_values)
+        vote = self.step_T_sample
+        last_mode = (hip.STEP_LAST_MAJORITY if vote is None or vote == "majority"
+                     else hip.STEP_LAST_CONFIDENCE if vote == "confidence" else hip.STEP_LAST_KEEP)
+        coeffs = []
+        for t in t_values:
+            a, c = self.diffusion.posterior_coeffs(t)
+            coeffs.append((a, c, hip.STEP_SAMPLE if t > 1 else last_mode))
+        noise = None
+        if self.rng == "torch_cpu":
+            n_draws = sum(1 for t in t_values if t > 1)
+            if n_draws:
+                gN, first = self.noise_slice if self.noise_slice is not None else (N, 0)
+                host = torch.empty((n_draws, gN, H * W * K), dtype=torch.float32)
+                for j in range(n_draws):        # one [gN*H*W, K] draw per step, like torch.multinomial
+                    host[j].view(-1).exponential_(1)
+                noise = host[:, first:first + N].contiguous().to(eng.device)
+        elif self.rng != "philox":
+            raise ValueError(f"unknown rng mode {self.rng!r}")
+        with eng.enter():
+            eng.set_inputs(self._to_index(x, eng.device), condition.to(eng.device), feature_condition)
+            eng.set_tables([float(t) for t in t_values], coeffs)
+            eng.run(S, noise=noise, philox_seed=self.philox_seed, sample_offset=self.sample_offset,
+                    use_graph=self.use_graph)
+            if t_values[-1] > 1 or last_mode == hip.STEP_LAST_KEEP:
+                idx = eng.xt.reshape(N, H, W).long()
+                out = torch.nn.functional.one_hot(idx, K).permute(0, 3, 1, 2).to(torch.float32)
+            elif last_mode == hip.STEP_LAST_CONFIDENCE:
+                out = eng.out_probs.clone().permute(0, 3, 1, 2)          # BCHW view of channels-last memory, like the reference
+            else:
+                out = eng.out_onehot.clone().permute(0, 3, 1, 2)
+        eng.leave()
+        if out.device != x.device:
+            out = out.to(x.device)
+        return {"diffusion_out": out}
+
+
+def build_model(
+        time_steps: int,
+        schedule: str,
+        schedule_params: Union[dict, None],
+        input_shapes: List[Tuple[int, int, int]],
+        cond_encoded_shape,
+        backbone: str,
+        backbone_params: Dict[str, Any],
+        dataset_file: str,
+        step_T_sample: str = None,
+        feature_cond_encoder: dict = None
+) -> DenoisingModel:
+    """Same signature and dispatch as the reference's backbone registry (builder.py:14-51)."""
+    img_shape, label_shape = input_shapes
+    img_channels = img_shape[0]
+    num_classes = label_shape[0]
+    diffusion = DiffusionModel(schedule, time_steps, num_classes, schedule_params=schedule_params)
+    if backbone == "unet_openai":
+        spec = make_unet_spec(
+            image_size=min(img_shape[1], img_shape[2]),
+            in_channels=num_classes + img_channels,
+            out_channels=num_classes,
+            num_res_blocks=2,
+            cond_encoded_shape=cond_encoded_shape,
+            feature_cond_encoder=feature_cond_encoder,
+            **backbone_params
+        )
+        model = UNetModel(spec)
+    else:
+        raise NotImplementedError(f"backbone {backbone}")
+    LOGGER.info("%s trainable params: %d", backbone, spec.num_params())
+    return DenoisingModel(diffusion, model, dataset_file, step_T_sample)

@@ -1,0 +1,174 @@
+/*
+ * ccdm_hip.h — C ABI of libccdm_hip.so: the MI355X (gfx950) kernels of the categorical reverse-diffusion
+ * sampler, plus the step executor ("engine") that replays them for T denoise steps.
+ *
+ * Plain pointers and sizes only; no torch types.  Every pointer marked `dev` is HIP device memory owned by
+ * the caller (the Python host allocates it through torch); the library never allocates device memory and
+ * keeps no global state besides a thread-local error string.  Every launch goes on the `stream` the caller
+ * passes (a hipStream_t cast to void*; NULL = default stream).  Return value: 0 = ok, negative = error
+ * (text via ccdm_last_error_string()).
+ *
+ * The reference (/root/reference, pure Python on torch) has no FFI; each entry point cites the reference
+ * function whose arithmetic it replaces.  Activations are NHWC fp32; the reference's BCHW tensors are
+ * re-laid-out once at the boundary (ccdm_nchw_to_nhwc / the Python host).
+ */
+#ifndef CCDM_HIP_H
+#define CCDM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CCDM_ABI_VERSION 1
+#define CCDM_MAX_CHANNELS 1024      /* max C0+C1 of a GroupNorm'ed conv input */
+#define CCDM_STATS_MAX_SLICES 16    /* partial-statistics slices per sample */
+
+int ccdm_version(void);
+const char* ccdm_last_error_string(void);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Per-channel statistics of an NHWC tensor, the form every GroupNorm consumer reads:
+ *   stats[n][s][c][0] = sum_x, stats[n][s][c][1] = sum_x^2 over the pixels slice s covered (fp64),
+ *   s in [0, slices).  The consumer adds the slices in ascending s — a fixed order, so results are
+ *   run-to-run deterministic (no floating-point atomics anywhere).
+ * Replaces the statistics half of GroupNorm32 (unet_openai/nn.py:17-19 -> torch group_norm).
+ * ------------------------------------------------------------------------------------------------- */
+int ccdm_gn_stats(const float* x /*dev [N,HW,C]*/, int N, int HW, int C, int slices,
+                  double* stats /*dev [N,slices,C,2]*/, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Fused  [GroupNorm(32 groups) -> (FiLM) -> SiLU ->]  conv KxK  [+bias +emb | +residual]  (+output stats)
+ * on NHWC fp32, implicit GEMM on the matrix cores.
+ * Replaces: ResBlock.in_layers / out_layers (unet.py:186-219, 242-262), skip_connection 1x1 (:221-228),
+ * Downsample.op (:137-146), Upsample nearest-x2 + conv (:106-116), AttentionBlock.norm+qkv and proj_out
+ * (:291-300, conv1d k=1 == 1x1 conv over tokens), the stem conv (:517) and the head GN-SiLU-conv (:701-707).
+ * ------------------------------------------------------------------------------------------------- */
+enum { CCDM_ACT_NONE = 0, CCDM_ACT_SILU = 1 };
+enum { CCDM_PREC_F32 = 0,      /* v_mfma_f32_32x32x2_f32: exact fp32 products and accumulation          */
+       CCDM_PREC_F16X3 = 1 };  /* fp16 hi/lo split, 3 x v_mfma_f32_32x32x16_f16, fp32 accumulate (~2^-22) */
+
+typedef struct ccdm_conv_args {
+    /* input: virtual channel concat [in0 | in1] (in1 may be NULL); both [N,Hin,Win,C*] */
+    const float* in0; const float* in1; int32_t C0; int32_t C1;
+    /* GroupNorm over the concatenated channels: partial stats of each source (NULL = no normalisation) */
+    const double* stats0; const double* stats1; int32_t slices0; int32_t slices1;
+    const float* gamma; const float* beta;          /* dev [C0+C1] */
+    float eps; int32_t act;                         /* CCDM_ACT_* applied after the affine */
+    /* FiLM (use_scale_shift_norm): h = GN(h)*(1+scale)+shift, scale|shift = emb row [film_off, +2*C) */
+    int32_t film; int32_t film_off;
+    /* geometry */
+    int32_t N, Hin, Win, Hout, Wout;
+    int32_t ksize;                                  /* 1 or 3 (pad = ksize/2) */
+    int32_t stride;                                 /* 1 or 2 */
+    int32_t up;                                     /* 1: nearest x2 upsample of the input on load */
+    /* weights, packed by ccdm_pack_conv_weight for `prec` */
+    const void* w; const float* bias; int32_t Cout; int32_t prec;
+    /* epilogue */
+    const float* emb_table; int32_t emb_stride; int32_t emb_off;   /* += emb_table[row*emb_stride + emb_off + c]; emb_off<0: none */
+    const int32_t* emb_row_of_sample;               /* dev [N] or NULL (row = 0) ; row += *step_ptr */
+    const int32_t* step_ptr;                        /* dev scalar or NULL (0) */
+    const float* resid;                             /* dev [N,Hout,Wout,Cout] added last, or NULL */
+    float* out;                                     /* dev [N,Hout,Wout,Cout] */
+    double* out_stats; int32_t out_slices;          /* dev [N,out_slices,Cout,2] or NULL; out_slices = ccdm_conv_slices() */
+} ccdm_conv_args;
+
+/* number of statistics slices the conv kernel produces for an Hout x Wout output (depends only on the
+ * spatial size, never on N, so sharding the batch does not change any rounding) */
+int ccdm_conv_slices(int Hout, int Wout, int stride, int ksize);
+int ccdm_conv2d(const ccdm_conv_args* a, void* stream);
+
+/* host-side weight packing.  `oihw` = reference layout [Cout,Cin,k,k] (conv2d) / [Cout,Cin,1] (conv1d).
+ * Returns the packed size in bytes (call with out=NULL to query). */
+size_t ccdm_pack_conv_weight(const float* oihw, int Cout, int Cin, int ksize, int prec, void* out);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Self-attention core over tokens, softmax(q k^T * ch^-1/2) v per head, streaming (score matrix never in HBM).
+ * qkv: [N,T,3C] (the qkv 1x1 conv output, NHWC), out: [N,T,C].
+ * order 0 = QKVAttentionLegacy (channel = head*3ch + {q,k,v}*ch + c, unet.py:343-360),
+ * order 1 = QKVAttention        (channel = {q,k,v}*C + head*ch + c,   unet.py:376-395).
+ * ------------------------------------------------------------------------------------------------- */
+int ccdm_attention(const float* qkv, float* out, int N, int T, int C, int heads, int order, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Time conditioning for a list of steps (depends only on t, so computed once per run):
+ *   emb = Linear(SiLU(Linear(sinusoid(t))))                  unet.py:506-510,:758
+ *   out[s] = Wcat * SiLU(emb) + bcat                          all ResBlock.emb_layers at once, unet.py:205-211,:250
+ * `sinus` is timestep_embedding(t, model_channels) (nn.py:103-121), evaluated by the host with the same torch
+ * ops as the reference: t*freq reaches 1e3 rad, so a 1-ulp difference in exp() would already move cos/sin
+ * by 1e-5 — the table is [S, mc] floats, not worth a second libm.
+ * ------------------------------------------------------------------------------------------------- */
+int ccdm_time_table(const float* sinus /*dev [S,mc]*/, int S, int model_channels,
+                    const float* w0, const float* b0, const float* w2, const float* b2,  /* dev, reference [out,in] layout */
+                    const float* wcat /*dev [E,4mc]*/, const float* bcat /*dev [E]*/, int E,
+                    float* emb_out /*dev [S,4mc] or NULL*/, float* out /*dev [S,E]*/, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Fused epilogue of one denoise step, one thread per pixel:
+ *   x0 = softmax_K(head) (or head itself)                                     unet.py:706
+ *   P  = theta_post_prob(x_t, x0, t)   (O(K) closed form, in registers)       diffusion_denoising.py:99-128
+ *   P  = max(P, 1e-12); P^ = P / sum_K P                                      :204 ; torch Categorical
+ *   t>1 : x_{t-1} = argmax_k P^_k / E_k (first index wins)                    one_hot_categorical.py:30-32
+ *   t==1: "confidence" -> P^ (fp32) ; "majority" -> one_hot(argmax P^) int64  :46-54 ; diffusion_denoising.py:208-212
+ * E is read from `noise` (host-drawn Exp(1), order ((n*H+h)*W+w)*K+k) or generated with Philox4x32-10.
+ * ------------------------------------------------------------------------------------------------- */
+enum { CCDM_STEP_SAMPLE = 0, CCDM_STEP_LAST_CONFIDENCE = 1, CCDM_STEP_LAST_MAJORITY = 2, CCDM_STEP_LAST_KEEP = 3,
+       CCDM_STEP_SOFTMAX_ONLY = 4 /* out_probs = x0 (the U-Net output itself): forward_step, diffusion_denoising.py:161-162 */ };
+
+typedef struct ccdm_post_args {
+    const float* head;           /* dev [N,HW,K] head conv output (logits, or probabilities if !softmax) */
+    int32_t softmax;             /* 1: apply softmax over K first */
+    const uint8_t* xt;           /* dev [N,HW] class index of x_t */
+    int32_t N, HW, K;
+    /* per-step coefficients: row = *step_ptr (0 if NULL) of step_table = {alpha_t, cumalpha_tm1, mode, 0} */
+    const float* step_table; const int32_t* step_ptr;
+    /* noise */
+    const float* noise; int64_t noise_step_stride;        /* dev or NULL -> Philox */
+    uint64_t philox_seed; uint32_t sample_offset;         /* global index of sample 0 (batch sharding) */
+    /* outputs */
+    uint8_t* xt_next;            /* dev [N,HW] (may alias xt) */
+    float* xin; int32_t xin_stride;  /* dev [N,HW,xin_stride]: one-hot written to channels [0,K) ; or NULL */
+    float* out_probs;            /* dev [N,HW,K] fp32   (confidence) or NULL */
+    int64_t* out_onehot;         /* dev [N,HW,K] int64  (majority)   or NULL */
+    float* posterior_out;        /* dev [N,HW,K] optional debug/teacher-forcing tap of P^ , or NULL */
+} ccdm_post_args;
+
+int ccdm_posterior_sample(const ccdm_post_args* a, void* stream);
+
+/* boundary re-layout helpers */
+int ccdm_nchw_to_nhwc(const float* src, float* dst, int N, int C, int HW, int dst_stride, int dst_off, void* stream);
+int ccdm_onehot_to_xin(const uint8_t* idx, float* xin, int N, int HW, int K, int xin_stride, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Step executor.  The host describes one denoise step as a list of ops (fully resolved device pointers);
+ * ccdm_engine_run replays it n_steps times with a device-resident step counter, optionally through a
+ * HIP graph captured on first use.  One engine per (model, N, H, W); single-threaded like the
+ * reference's DenoisingModel.forward_denoising loop (diffusion_denoising.py:189-212).
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct ccdm_engine ccdm_engine;
+
+ccdm_engine* ccdm_engine_create(int32_t* step_counter /*dev scalar*/);
+void ccdm_engine_destroy(ccdm_engine* e);
+int ccdm_engine_add_conv(ccdm_engine* e, const ccdm_conv_args* a);          /* step_ptr is overridden with the engine's counter */
+int ccdm_engine_add_attention(ccdm_engine* e, const float* qkv, float* out, int N, int T, int C, int heads, int order);
+int ccdm_engine_set_epilogue(ccdm_engine* e, const ccdm_post_args* a);      /* run after the ops of each step */
+int ccdm_engine_num_ops(const ccdm_engine* e);
+/* per-run mutable fields of the epilogue (everything else is fixed at build time) */
+int ccdm_engine_set_run(ccdm_engine* e, const float* noise, int64_t noise_step_stride,
+                        uint64_t philox_seed, uint32_t sample_offset,
+                        float* out_probs, int64_t* out_onehot, float* posterior_out);
+/* run `n_steps` denoise steps starting at table row `first_row`; use_graph: 0 eager launches, 1 HIP graph of one step */
+int ccdm_engine_run(ccdm_engine* e, int first_row, int n_steps, int with_epilogue, int use_graph, void* stream);
+/* timing taps: record HIP events around every launch of op `op_index` during the next run (max `capacity`
+ * launches); ccdm_engine_profile_read returns the number of samples and their mean/min/max in ms. */
+int ccdm_engine_profile_op(ccdm_engine* e, int op_index, int capacity);
+int ccdm_engine_profile_read(ccdm_engine* e, double* mean_ms, double* min_ms, double* max_ms);
+/* describe op i: writes a short text ("conv3x3 32->32 @128x128 gn silu ...") */
+int ccdm_engine_describe_op(const ccdm_engine* e, int i, char* buf, int buflen);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CCDM_HIP_H */

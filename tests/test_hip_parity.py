@@ -1,0 +1,422 @@
+"""GPU parity tests: every kernel and the whole sampler, through the C ABI, against the oracle on the
+same seeded inputs and against the committed golden fixtures.  Run with `-m gpu` on an MI355X.
+
+Tolerances: fp32 kernels differ from torch-CPU only by summation order -> 2e-5 abs on O(1) activations
+per layer, 1e-4 on the U-Net's output probabilities (north_star); class indices bit-exact given identical
+probabilities and noise."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ccdm_oracle as O  # noqa: E402
+from ccdm_stochastic_segmentation_amd import hip, build_model, make_unet_spec, make_synthetic_state_dict  # noqa: E402
+from tests.golden_util import BLOCK_CASES, block_tensors  # noqa: E402
+
+LIDC_BP = dict(base_channels=32, channel_mult=None, attention_resolutions=[32, 16, 8], num_heads=1,
+               num_head_channels=32, softmax_output=True)
+LIDC_CFG = dict(num_heads=1, num_head_channels=32)
+
+
+@pytest.fixture(scope="module")
+def U():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU")
+    from tests import hip_util
+    hip.load()
+    return hip_util
+
+
+def unpack(bits, shape):
+    return np.unpackbits(bits)[: int(np.prod(shape))].reshape(shape).astype(np.int64)
+
+
+def rnd(rng, *shape, scale=1.0):
+    return torch.from_numpy((scale * rng.standard_normal(shape)).astype(np.float32))
+
+
+# ------------------------------------------------------------------------------------------ gn stats
+@pytest.mark.parametrize("C,H,W,slices", [(32, 16, 16, 1), (96, 8, 8, 4), (224, 5, 7, 3), (448, 8, 16, 1), (4, 9, 9, 2)])
+def test_gn_stats(U, C, H, W, slices):
+    rng = np.random.default_rng(C + H)
+    x = rnd(rng, 3, C, H, W) * 3 + 0.5
+    st = U.gn_stats(U.nhwc(x), slices).cpu().sum(1)
+    U.sync()
+    xd = x.double()
+    np.testing.assert_allclose(st[..., 0].numpy(), xd.sum((2, 3)).numpy(), rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(st[..., 1].numpy(), (xd * xd).sum((2, 3)).numpy(), rtol=1e-12, atol=1e-9)
+
+
+# ------------------------------------------------------------------------------------------ conv
+CONV_CASES = [
+    # cin0, cin1, cout, H, W, k, stride, up, gn, act, emb, resid
+    (32, 0, 32, 32, 32, 3, 1, 0, 1, 1, 1, 0),     # ResBlock conv1 @ geometry A
+    (32, 0, 32, 64, 64, 3, 1, 0, 1, 1, 0, 1),     # ResBlock conv2 + identity residual, multi-tile slices
+    (64, 32, 32, 32, 32, 3, 1, 0, 1, 1, 1, 0),    # decoder: virtual concat, 3 ch/group across the seam
+    (128, 96, 96, 16, 16, 3, 1, 0, 1, 1, 1, 0),   # 224 = 128+96, 7 ch/group straddling the seam, geometry B
+    (128, 0, 128, 8, 8, 3, 1, 0, 1, 1, 1, 1),     # geometry C, 4 n-tiles
+    (32, 0, 32, 32, 32, 3, 2, 0, 0, 0, 0, 0),     # Downsample
+    (64, 0, 64, 16, 16, 3, 1, 1, 0, 0, 0, 0),     # Upsample (nearest x2 on load)
+    (64, 32, 32, 32, 32, 1, 1, 0, 0, 0, 0, 0),    # 1x1 skip on a concat input
+    (96, 0, 288, 16, 16, 1, 1, 0, 1, 0, 0, 0),    # qkv: GN without SiLU, 9 n-tiles -> 3 groups
+    (4, 0, 32, 32, 32, 3, 1, 0, 0, 0, 0, 0),      # stem (3 real channels padded to 4)
+    (32, 0, 2, 32, 32, 3, 1, 0, 1, 1, 0, 0),      # head K=2
+    (32, 0, 20, 24, 40, 3, 1, 0, 1, 1, 0, 0),     # head K=20, ragged tile edges
+    (32, 0, 32, 20, 36, 3, 1, 0, 1, 1, 1, 1),     # ragged H,W everywhere
+    (384, 64, 64, 8, 16, 3, 1, 0, 1, 1, 1, 0),    # DINO-widened block: 448 ch, 14 ch/group
+    (160, 0, 160, 8, 8, 1, 1, 0, 0, 0, 0, 0),     # 5 n-tiles -> padded to 8
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "-".join(map(str, c)))
+def test_conv(U, case):
+    c0, c1, cout, H, W, k, stride, up, gn, act, emb, resid = case
+    rng = np.random.default_rng(sum(case))
+    N = 2
+    cin = c0 + c1
+    xa = rnd(rng, N, c0, H, W) * 1.5 + 0.3
+    xb = rnd(rng, N, c1, H, W) * 0.7 - 0.2 if c1 else None
+    w = rnd(rng, cout, cin, k, k) / np.sqrt(cin * k * k)
+    b = rnd(rng, cout, scale=0.1)
+    gamma, beta = 1 + rnd(rng, cin, scale=0.1), rnd(rng, cin, scale=0.1)
+    x = torch.cat([xa, xb], 1) if c1 else xa
+    # ---- oracle (torch CPU) ----
+    h = x
+    if gn:
+        h = F.group_norm(h, 32, gamma, beta, 1e-5)
+    if act:
+        h = F.silu(h)
+    if up:
+        h = F.interpolate(h, scale_factor=2, mode="nearest")
+    ref = F.conv2d(h, w, b, stride=stride, padding=k // 2)
+    embt = rnd(rng, N, cout) if emb else None
+    if emb:
+        ref = ref + embt[:, :, None, None]
+    res = rnd(rng, *ref.shape) if resid else None
+    if resid:
+        ref = ref + res
+    # ---- HIP ----
+    srcs = [U.nhwc(xa)] + ([U.nhwc(xb)] if c1 else [])
+    stats = [U.gn_stats(s, 3 if s.shape[1] * s.shape[2] >= 64 else 1) for s in srcs] if gn else None
+    out, ost = U.conv2d(srcs, w.numpy(), b.numpy(), k, stats=stats, gamma=gamma.numpy(), beta=beta.numpy(),
+                        act=hip.ACT_SILU if act else hip.ACT_NONE, stride=stride, up=bool(up),
+                        emb=embt.numpy() if emb else None, emb_rows=np.arange(N) if emb else None,
+                        resid=U.nhwc(res) if resid else None)
+    got = U.bchw(out)
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=0, atol=2e-5)
+    # fused output statistics == statistics of what was stored
+    st = ost.cpu().sum(1)
+    gd = got.double()
+    np.testing.assert_allclose(st[..., 0].numpy(), gd.sum((2, 3)).numpy(), rtol=1e-10, atol=1e-8)
+    np.testing.assert_allclose(st[..., 1].numpy(), (gd * gd).sum((2, 3)).numpy(), rtol=1e-10, atol=1e-8)
+
+
+def test_conv_rejects_bad_args(U):
+    x = torch.zeros((1, 8, 8, 6), device=U.DEV)
+    with pytest.raises(hip.CcdmHipError, match="multiples of 4"):
+        U.conv2d([x], np.zeros((32, 6, 3, 3), np.float32), np.zeros(32, np.float32), 3)
+    x = torch.zeros((1, 8, 8, 8), device=U.DEV)
+    with pytest.raises(hip.CcdmHipError, match="ksize"):
+        U.conv2d([x], np.zeros((32, 8, 5, 5), np.float32), np.zeros(32, np.float32), 5)
+
+
+# ------------------------------------------------------------------------------------------ attention
+@pytest.mark.parametrize("C,T,order", [(96, 256, 0), (128, 64, 0), (64, 64, 1), (32, 100, 0), (96, 2048, 0)])
+def test_attention_core(U, C, T, order):
+    rng = np.random.default_rng(C + T)
+    heads = C // 32
+    qkv = rnd(rng, 2, 3 * C, T) * 1.3
+    ref = (O.qkv_attention_new if order else O.qkv_attention_legacy)(qkv, heads)        # [N, C, T]
+    got = U.attention(qkv.permute(0, 2, 1).contiguous().to(U.DEV), heads, order).cpu().permute(0, 2, 1)
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=0, atol=3e-6)
+
+
+# ------------------------------------------------------------------------------------------ blocks (goldens)
+def _run_block(U, kind, kw, sd, x, emb):
+    xs = U.nhwc(x)
+    st = U.gn_stats(xs, 1)
+    p = "b."
+    if kind == "res":
+        e = F.linear(F.silu(emb), sd[p + "emb_layers.1.weight"], sd[p + "emb_layers.1.bias"])   # host side of the test only
+        N = x.shape[0]
+        film = kw["film"]
+        h, hst = U.conv2d([xs], sd[p + "in_layers.2.weight"].numpy(), sd[p + "in_layers.2.bias"].numpy(), 3, stats=[st],
+                          gamma=sd[p + "in_layers.0.weight"].numpy(), beta=sd[p + "in_layers.0.bias"].numpy(), act=hip.ACT_SILU,
+                          emb=None if film else e.numpy(), emb_rows=np.arange(N))
+        skip = xs
+        if (p + "skip_connection.weight") in sd:
+            skip, _ = U.conv2d([xs], sd[p + "skip_connection.weight"].numpy(), sd[p + "skip_connection.bias"].numpy(), 1, want_stats=False)
+        y, _ = U.conv2d([h], sd[p + "out_layers.3.weight"].numpy(), sd[p + "out_layers.3.bias"].numpy(), 3, stats=[hst],
+                        gamma=sd[p + "out_layers.0.weight"].numpy(), beta=sd[p + "out_layers.0.bias"].numpy(), act=hip.ACT_SILU,
+                        film=e.numpy() if film else None, emb_rows=np.arange(N), resid=skip)
+        return U.bchw(y)
+    if kind == "attn":
+        C_ = kw["ch"]
+        qkv, _ = U.conv2d([xs], sd[p + "qkv.weight"].numpy(), sd[p + "qkv.bias"].numpy(), 1, stats=[st],
+                          gamma=sd[p + "norm.weight"].numpy(), beta=sd[p + "norm.bias"].numpy(), want_stats=False)
+        N, H, W, _ = qkv.shape
+        a = U.attention(qkv.reshape(N, H * W, 3 * C_), C_ // 32, 1 if kw["new"] else 0).reshape(N, H, W, C_)
+        y, _ = U.conv2d([a], sd[p + "proj_out.weight"].numpy(), sd[p + "proj_out.bias"].numpy(), 1, resid=xs)
+        return U.bchw(y)
+    if kind == "down":
+        y, _ = U.conv2d([xs], sd[p + "op.weight"].numpy(), sd[p + "op.bias"].numpy(), 3, stride=2)
+        return U.bchw(y)
+    y, _ = U.conv2d([xs], sd[p + "conv.weight"].numpy(), sd[p + "conv.bias"].numpy(), 3, up=True)
+    return U.bchw(y)
+
+
+@pytest.mark.parametrize("tag", list(BLOCK_CASES))
+def test_blocks_vs_reference_golden(U, golden, tag):
+    kind, kw, xs, seed = BLOCK_CASES[tag]
+    w, x, emb = block_tensors(seed, golden.meta["block_shapes"][tag], xs)
+    sd = {"b." + k: torch.from_numpy(v) for k, v in w.items()}
+    y = _run_block(U, kind, kw, sd, torch.from_numpy(x), torch.from_numpy(emb))
+    np.testing.assert_allclose(y.numpy(), golden["g3_blocks"][tag + ".y"], rtol=0, atol=3e-5)
+
+
+# ------------------------------------------------------------------------------------------ time tables
+def test_time_table(U, golden):
+    spec = make_unet_spec(image_size=128, in_channels=3, out_channels=2, **LIDC_BP)
+    sd = {k: torch.from_numpy(v) for k, v in make_synthetic_state_dict(spec, 0).items()}
+    from ccdm_stochastic_segmentation_amd.engine import timestep_embedding_host
+    t = torch.from_numpy(golden["g2_time_embed"]["t"])
+    sin = timestep_embedding_host(t, 32)
+    assert np.array_equal(sin.numpy(), golden["g2_time_embed"]["emb32"])            # host sinusoid: bit-exact
+    names = [n for n, l in spec.all_layers() if l.kind == "res"]
+    wcat = torch.cat([sd[n + ".emb_layers.1.weight"] for n in names]).to(U.DEV)
+    bcat = torch.cat([sd[n + ".emb_layers.1.bias"] for n in names]).to(U.DEV)
+    E, S = wcat.shape[0], len(t)
+    emb = torch.empty((S, 128), device=U.DEV)
+    out = torch.empty((S, E), device=U.DEV)
+    dv = [sd[k].to(U.DEV) for k in ("time_embed.0.weight", "time_embed.0.bias", "time_embed.2.weight", "time_embed.2.bias")]
+    sin_d = sin.to(U.DEV)
+    hip.check(hip.load().ccdm_time_table(sin_d.data_ptr(), S, 32, *(d.data_ptr() for d in dv), wcat.data_ptr(), bcat.data_ptr(),
+                                         E, emb.data_ptr(), out.data_ptr(), 0), "time_table")
+    U.sync()
+    np.testing.assert_allclose(emb.cpu().numpy(), golden["g2_time_embed"]["time_embed"], rtol=0, atol=2e-6)
+    e_ref = O.time_embed(sd, t)
+    ref = F.linear(F.silu(e_ref), wcat.cpu(), bcat.cpu())
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=0, atol=5e-6)
+
+
+# ------------------------------------------------------------------------------------------ epilogue
+@pytest.mark.parametrize("K", [2, 3, 20])
+def test_posterior_matches_oracle_and_reference_golden(U, golden, K):
+    rng = np.random.default_rng(K)
+    _, alphas, cum = O.make_schedule("cosine", 250)
+    N, H, W = 2, 12, 10
+    xt = torch.from_numpy(rng.integers(0, K, (N, H, W)))
+    logits = rnd(rng, N, K, H, W) * 3
+    x0 = torch.softmax(logits, 1)
+    for t in (250, 125, 2, 1):
+        a, c = O.posterior_coeffs(alphas, cum, t)
+        ref = torch.clamp(O.theta_post_prob(O.one_hot_bchw(xt, K), x0, a, c), min=1e-12)
+        ref = O.normalise_probs(ref, order="cascade")
+        r = U.posterior_sample(U.nhwc(logits).reshape(N, H * W, K), xt.to(torch.uint8).reshape(N, -1).to(U.DEV), a, c,
+                               hip.STEP_LAST_CONFIDENCE)
+        np.testing.assert_allclose(r["probs"].reshape(N, H, W, K).numpy(), ref.numpy(), rtol=2e-6, atol=1e-9)
+        np.testing.assert_allclose(r["probs"].sum(-1).numpy(), 1.0, atol=1e-6)
+        # against the reference's own O(K^2) posterior
+        ref2 = O.normalise_probs(torch.clamp(O.theta_post_prob_ref(O.one_hot_bchw(xt, K), x0, a, c), min=1e-12))
+        np.testing.assert_allclose(r["probs"].reshape(N, H, W, K).numpy(), ref2.numpy(), rtol=0, atol=3e-6)
+        rm = U.posterior_sample(U.nhwc(logits).reshape(N, H * W, K), xt.to(torch.uint8).reshape(N, -1).to(U.DEV), a, c,
+                                hip.STEP_LAST_MAJORITY)
+        assert rm["onehot"].dtype == torch.int64
+        assert torch.equal(rm["onehot"].argmax(-1), r["probs"].argmax(-1))
+    # softmax-only mode returns the U-Net output itself
+    rs = U.posterior_sample(U.nhwc(logits).reshape(N, H * W, K), xt.to(torch.uint8).reshape(N, -1).to(U.DEV), 0.0, 1.0,
+                            hip.STEP_SOFTMAX_ONLY)
+    np.testing.assert_allclose(rs["probs"].reshape(N, H, W, K).permute(0, 3, 1, 2).numpy(), x0.numpy(), rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("K", [2, 20])
+def test_sampler_bit_exact_on_reference_golden(U, golden, K):
+    """Same posterior probabilities + same noise -> identical class indices (T2 steps 2-4).  The kernel is
+    driven with a = 0, c = 1 (t == 1 coefficients: posterior == its input) and softmax off, so its input
+    *is* the posterior the reference sampled from."""
+    g = golden["g6_sampler"]
+    probs = torch.from_numpy(g[f"K{K}_probs"])          # already clamped at 1e-12, [2,K,12,10]
+    noise = torch.from_numpy(g[f"K{K}_noise"])
+    N, _, H, W = probs.shape
+    xt = torch.zeros((N, H * W), dtype=torch.uint8, device=U.DEV)
+    if K & (K - 1) == 0:
+        # K power of two: (1/K) * (K * p) is exact, so the kernel's posterior stage is the identity
+        r = U.posterior_sample(U.nhwc(probs).reshape(N, H * W, K), xt, 0.0, 1.0, hip.STEP_SAMPLE, softmax=False,
+                               noise=noise.to(U.DEV))
+        assert np.array_equal(r["posterior"].reshape(N, H, W, K).numpy(), g[f"K{K}_phat"])          # bit-exact P^
+        assert np.array_equal(r["xt_next"].reshape(N, H, W).numpy().astype(np.int64), g[f"K{K}_idx"])   # bit-exact indices
+        onehot = r["xin"][..., :K].reshape(N, H, W, K).argmax(-1)
+        assert np.array_equal(onehot.numpy(), g[f"K{K}_idx"])
+    else:
+        r = U.posterior_sample(U.nhwc(probs).reshape(N, H * W, K), xt, 0.0, 1.0, hip.STEP_SAMPLE, softmax=False,
+                               noise=noise.to(U.DEV))
+        ph = r["posterior"].reshape(N, H, W, K)
+        np.testing.assert_allclose(ph.numpy(), g[f"K{K}_phat"], rtol=4e-7, atol=0)
+        # indices must equal argmax of the kernel's own P^ / E, evaluated on the host with IEEE division
+        idx = torch.argmax(ph / noise.reshape(N, H, W, K), -1)
+        assert torch.equal(idx, r["xt_next"].reshape(N, H, W).long())
+        # and may differ from the reference only where the race is a near-tie (last-ulp normalisation order)
+        diff = (idx.numpy() != g[f"K{K}_idx"])
+        assert diff.mean() < 0.01
+
+
+def test_philox_stream_matches_oracle(U):
+    """Throughput-mode RNG: the device Philox4x32-10 stream equals the numpy restatement; indices equal
+    argmax(P^/E) with the oracle's E wherever the race is not a last-ulp tie."""
+    K, N, HW = 20, 3, 64
+    rng = np.random.default_rng(0)
+    logits = rnd(rng, N, HW, K)
+    xt = torch.from_numpy(rng.integers(0, K, (N, HW))).to(torch.uint8)
+    _, alphas, cum = O.make_schedule("cosine", 250)
+    a, c = O.posterior_coeffs(alphas, cum, 100)
+    r = U.posterior_sample(logits.to(U.DEV), xt.to(U.DEV), a, c, hip.STEP_SAMPLE, philox_seed=0x1234567890ABCDEF,
+                           sample_offset=5, step=3)
+    e = torch.from_numpy(O.philox_exponential(0x1234567890ABCDEF, 3, 5, N, HW, K))
+    q = r["posterior"] / e
+    top2 = torch.topk(q, 2, -1).values
+    clear = (top2[..., 0] - top2[..., 1]) > 1e-5 * top2[..., 0]
+    assert clear.float().mean() > 0.99
+    assert torch.equal(q.argmax(-1)[clear], r["xt_next"].long()[clear])
+    # different sample_offset -> different stream; same offset -> identical (sharding invariance)
+    r2 = U.posterior_sample(logits[1:].contiguous().to(U.DEV), xt[1:].contiguous().to(U.DEV), a, c, hip.STEP_SAMPLE,
+                            philox_seed=0x1234567890ABCDEF, sample_offset=6, step=3)
+    assert torch.equal(r2["xt_next"], r["xt_next"][1:])
+
+
+# ------------------------------------------------------------------------------------------ whole network
+@pytest.fixture(scope="module")
+def lidc_model():
+    model = build_model(250, "cosine", {"s": 0.008}, [(1, 128, 128), (2, 128, 128)], (1, 128, 128), "unet_openai", LIDC_BP,
+                        "datasets.lidc", "confidence", None)
+    sd = {k: torch.from_numpy(v) for k, v in make_synthetic_state_dict(model.unet.spec, 0).items()}
+    model.unet.load_state_dict(sd, strict=True)
+    return model.to("cuda:0").eval(), sd
+
+
+def test_unet_step_vs_reference_golden(U, golden, lidc_model):
+    model, sd = lidc_model
+    g = golden["g4_unet_step_lidc"]
+    rng = np.random.default_rng(1234)
+    image = torch.from_numpy(rng.uniform(-1, 1, (2, 1, 128, 128)).astype(np.float32))
+    idx = torch.from_numpy(rng.integers(0, 2, (2, 128, 128)))
+    out = model(O.one_hot_bchw(idx, 2).to(U.DEV), image.to(U.DEV), t=torch.full((2,), 37.0), validation=True)["diffusion_out"]
+    err = np.abs(out.cpu().numpy() - g["out"])
+    print("unet step max|dp| =", err.max())
+    assert err.max() < 1e-4                        # north_star tolerance on the output probabilities
+    # per-sample timesteps
+    tt = torch.tensor([37.0, 200.0])
+    out2 = model(O.one_hot_bchw(idx, 2).to(U.DEV), image.to(U.DEV), t=tt, validation=True)["diffusion_out"].cpu()
+    ref2 = O.unet_forward(sd, LIDC_CFG, O.one_hot_bchw(idx, 2), image, None, tt)["diffusion_out"]
+    assert (out2 - ref2).abs().max() < 1e-4
+
+
+def test_trajectory_teacher_forced_and_free_running(U, golden, lidc_model):
+    """G7: 10 strided steps, seed 42.  Teacher-forced (the reference's x_t fed to every step) the network
+    output stays within 1e-4 and, given the same noise, the sampled indices match except at near-ties;
+    free-running the final probabilities agree on almost every pixel."""
+    model, sd = lidc_model
+    g = golden["g7_trajectory_lidc"]
+    image = torch.from_numpy(np.random.default_rng(1234).uniform(-1, 1, (2, 1, 128, 128)).astype(np.float32))
+    t_values = list(g["t_values"])
+    torch.manual_seed(7)
+    stream = torch.empty(64).exponential_(1).numpy()
+    host_rng_ok = np.array_equal(stream, golden["g6_sampler"]["exp_stream_seed7"])
+    # ---- teacher forcing, one step at a time through forward_step + the oracle's x_t ----
+    worst = 0.0
+    for j, t in enumerate(t_values):
+        xt = torch.from_numpy(unpack(g[f"xt_{j}"], (2, 128, 128)))
+        out = model(O.one_hot_bchw(xt, 2).to(U.DEV), image.to(U.DEV), t=torch.full((2,), float(t)), validation=True)["diffusion_out"]
+        d = np.abs(out.cpu()[:, 0, ::16, ::16].numpy() - g[f"x0pred0_{j}"]).max()
+        worst = max(worst, d)
+    print("teacher-forced max|d x0pred| =", worst)
+    assert worst < 1e-4
+    if not host_rng_ok:
+        pytest.skip("host exponential_ stream differs from the fixture host; seeded trajectory not comparable")
+    # ---- free running, parity RNG ----
+    for vote in ("confidence", "majority"):
+        model.step_T_sample = vote
+        model.rng = "torch_cpu"
+        torch.manual_seed(42)
+        x = __import__("ccdm_stochastic_segmentation_amd").OneHotCategoricalBCHW(logits=torch.zeros(2, 2, 128, 128)).sample()
+        assert np.array_equal(x.argmax(1).numpy(), unpack(g["xT"], (2, 128, 128)))
+        out = model(x.to(U.DEV), image.to(U.DEV), t=torch.as_tensor(10010))["diffusion_out"].cpu()
+        if vote == "confidence":
+            assert out.dtype == torch.float32 and tuple(out.stride()) == tuple(g["out_stride"])
+            err = np.abs(out[:, 0].numpy() - g["out_confidence_c0"])
+            frac = (err > 1e-3).mean()
+            print(f"free-running: median|dp|={np.median(err):.2e} frac>1e-3={frac:.2e}")
+            assert np.median(err) < 1e-5 and frac < 0.02
+        else:
+            assert out.dtype == torch.int64
+            mism = (out.argmax(1).numpy() != unpack(g["out_majority"], (2, 128, 128))).mean()
+            print(f"free-running majority mismatch rate = {mism:.2e}")
+            assert mism < 0.02
+    model.step_T_sample = "confidence"
+
+
+def test_caller_contract_g9(U, golden, lidc_model):
+    model, _ = lidc_model
+    g = golden["g9_caller"]
+    from ccdm_stochastic_segmentation_amd import OneHotCategoricalBCHW
+    torch.manual_seed(0)
+    img = torch.from_numpy(np.random.default_rng(16).uniform(-1, 1, (2, 1, 128, 128)).astype(np.float32))
+    labels = torch.zeros(2, 4, 2, 128, 128)
+    S = 2
+    image = img.to(U.DEV).repeat_interleave(S, dim=0)
+    x = OneHotCategoricalBCHW(logits=torch.zeros(labels[:, 0].repeat_interleave(S, dim=0).shape)).sample().to(U.DEV)
+    assert np.array_equal(x.argmax(1).cpu().numpy(), unpack(g["xT"], (4, 128, 128)))
+    model.rng = "torch_cpu"
+    pred = model(x, image, t=torch.as_tensor(4))["diffusion_out"]
+    pred = pred.reshape(labels.shape[0], -1, *labels.shape[2:])
+    assert list(pred.shape) == list(g["shape"])
+    err = np.abs(pred[:, :, 0].cpu().numpy() - g["pred_c0"])
+    assert np.median(err) < 1e-5 and (err > 1e-3).mean() < 0.02
+
+
+def test_dino_concat_step_g8(U, golden):
+    g = golden["g8_unet_step_dino"]
+    fce = dict(type="dino", channels=384, output_stride=8, scale="single", target_layer=10)
+    model = build_model(250, "cosine", None, [(3, 64, 128), (20, 64, 128)], (3, 64, 128), "unet_openai",
+                        dict(LIDC_BP, channel_mult=[1, 1, 2, 2, 4, 4]), "datasets.cityscapes", "confidence", fce)
+    sd = {k: torch.from_numpy(v) for k, v in make_synthetic_state_dict(model.unet.spec, 8).items()}
+    model.unet.load_state_dict(sd, strict=True)
+    model = model.to("cuda:0").eval()
+    rng = np.random.default_rng(8)
+    img = torch.from_numpy(rng.standard_normal((1, 3, 64, 128)).astype(np.float32))
+    feat = torch.from_numpy(rng.standard_normal((1, 384, 8, 16)).astype(np.float32))
+    idx = torch.from_numpy(g["xt_idx"].astype(np.int64))
+    out = model(O.one_hot_bchw(idx, 20).to(U.DEV), img.to(U.DEV), feat.to(U.DEV), t=torch.full((1,), 120.0), validation=True)["diffusion_out"]
+    err = np.abs(out.cpu().numpy() - g["out"])
+    print("dino step max|dp| =", err.max())
+    assert err.max() < 1e-4
+    with pytest.raises(ValueError, match="feature_condition is required"):
+        model(O.one_hot_bchw(idx, 20).to(U.DEV), img.to(U.DEV), None, t=torch.full((1,), 120.0), validation=True)
+
+
+# ------------------------------------------------------------------------------------------ full-size properties
+def test_full_size_properties_c2(U, lidc_model):
+    """BASELINE config C2 size (N=64, 128x128, K=2), 6 strided steps, device RNG: size-independent properties —
+    probabilities normalised, run-to-run bit-identical, eager == HIP-graph replay, batch-shard invariance."""
+    model, _ = lidc_model
+    N = 64
+    rng = np.random.default_rng(5)
+    image = torch.from_numpy(rng.uniform(-1, 1, (N, 1, 128, 128)).astype(np.float32)).to(U.DEV)
+    x = O.one_hot_bchw(torch.from_numpy(rng.integers(0, 2, (N, 128, 128))), 2).to(U.DEV)
+    model.rng, model.philox_seed, model.step_T_sample = "philox", 99, "confidence"
+    outs = []
+    for graph in (False, False, True):
+        model.use_graph = graph
+        outs.append(model(x, image, t=torch.as_tensor(10006))["diffusion_out"].clone())
+    model.use_graph = False
+    a = outs[0]
+    assert torch.isfinite(a).all() and (a >= 0).all()
+    assert (a.sum(1) - 1).abs().max() < 1e-6
+    assert torch.equal(outs[0], outs[1]), "run-to-run nondeterminism"
+    assert torch.equal(outs[0], outs[2]), "graph replay differs from eager launches"
+    # shard invariance: samples [16,32) run alone with sample_offset=16 reproduce their slice bit-for-bit
+    model.sample_offset = 16
+    b = model(x[16:32], image[16:32], t=torch.as_tensor(10006))["diffusion_out"]
+    model.sample_offset = 0
+    assert torch.equal(b, a[16:32])
