@@ -16,16 +16,25 @@
 // :291-300; stem :517; head GN-SiLU-conv :701-707.   GroupNorm32 = nn.py:17-19,93-100.
 #include "ccdm_common.h"
 
+#include <cmath>
+#include <vector>
+
 namespace ccdm {
 
 static constexpr int CK = 32;          // input channels per K-chunk
-static constexpr int LDS_STRIDE = 33;  // floats per halo pixel (odd: conflict-free column reads)
+static constexpr int LDS_STRIDE = 33;  // F32: floats per halo pixel (odd: conflict-free column reads)
+// F16X3: bytes per halo pixel = 32 hi halfs | 32 lo halfs | 16 pad.  144 B = 36 dwords: the 16 pixels of a
+// ds_read_b128 lane group land on 16 disjoint 4-bank slots (36*p mod 64 is a permutation of multiples of 4).
+static constexpr int LDS_PIX_BYTES_F16 = 144;
+
+__device__ __forceinline__ int pix_bytes(int prec) { return prec == CCDM_PREC_F32 ? LDS_STRIDE * 4 : LDS_PIX_BYTES_F16; }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
 
 struct ConvK {   // kernel-side copy of ccdm_conv_args (+ derived)
     ccdm_conv_args a;
     int cin_pad, ntiles, slices, tiles_x, tiles_y;
+    const float* wscale;     // F16X3: [ntiles*32] powers of two undoing the per-output-channel weight pre-scale
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -65,13 +74,15 @@ __device__ __forceinline__ void compute_gn_affine(const ccdm_conv_args& a, int n
     }
 }
 
-template <int TH, int TW, int WAVES, int MI, int NI>
-__global__ __launch_bounds__(WAVES * 64) void k_conv_f32(const ConvK k) {
+template <int PREC, int TH, int TW, int WAVES, int MI, int NI>
+__global__ __launch_bounds__(WAVES * 64) void k_conv(const ConvK k) {
     const ccdm_conv_args& a = k.a;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int C = a.C0 + a.C1;
     float2* ab = reinterpret_cast<float2*>(smem);                              // [C] (only if stats0)
-    float* halo = reinterpret_cast<float*>(smem + (a.stats0 ? (size_t)C * 8 : 0));
+    char* halo_b = smem + (a.stats0 ? (size_t)C * 8 : 0);
+    float* halo = reinterpret_cast<float*>(halo_b);
+    constexpr int PIXB = PREC == CCDM_PREC_F32 ? LDS_STRIDE * 4 : LDS_PIX_BYTES_F16;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -90,7 +101,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_conv_f32(const ConvK k) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int p = (wave * MI + mi) * 32 + (lane & 31);
-        base[mi] = ((p / TW) * stride * HWt + (p % TW) * stride) * LDS_STRIDE + (lane >> 5);
+        if (PREC == CCDM_PREC_F32) base[mi] = ((p / TW) * stride * HWt + (p % TW) * stride) * LDS_STRIDE + (lane >> 5);
+        else base[mi] = ((p / TW) * stride * HWt + (p % TW) * stride) * PIXB + (lane >> 5) * 16;     // bytes
     }
     double s1[NI], s2[NI];
 #pragma unroll
@@ -129,27 +141,70 @@ __global__ __launch_bounds__(WAVES * 64) void k_conv_f32(const ConvK k) {
                     }
                     if (a.act == CCDM_ACT_SILU) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
                 }
-                float* d = halo + hp * LDS_STRIDE + 4 * q;
-                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                if (PREC == CCDM_PREC_F32) {
+                    float* d = halo + hp * LDS_STRIDE + 4 * q;
+                    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                } else {
+                    // fp16 hi/lo split: x = hi + lo + O(2^-22 |x|); both halves rounded to nearest
+                    f16x4 hi, lo;
+                    hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
+                    lo[0] = (_Float16)(v.x - (float)hi[0]); lo[1] = (_Float16)(v.y - (float)hi[1]);
+                    lo[2] = (_Float16)(v.z - (float)hi[2]); lo[3] = (_Float16)(v.w - (float)hi[3]);
+                    char* d = halo_b + hp * PIXB + 8 * q;
+                    *reinterpret_cast<f16x4*>(d) = hi;
+                    *reinterpret_cast<f16x4*>(d + 64) = lo;
+                }
             }
             __syncthreads();
-            // ---- taps x 16 k-steps of v_mfma_f32_32x32x2_f32 ----
-            const float* wc = reinterpret_cast<const float*>(a.w) + ((size_t)(c0 >> 1) * k.ntiles + nt0) * 64 + lane;
-            const size_t wtap = (size_t)(k.cin_pad >> 1) * k.ntiles * 64;
-            for (int tap = 0; tap < ks * ks; ++tap) {
-                const int toff = ((tap / ks) * HWt + (tap % ks)) * LDS_STRIDE;
-                const float* wt = wc + tap * wtap;
+            if (PREC == CCDM_PREC_F32) {
+                // ---- taps x 16 k-steps of v_mfma_f32_32x32x2_f32 ----
+                const float* wc = reinterpret_cast<const float*>(a.w) + ((size_t)(c0 >> 1) * k.ntiles + nt0) * 64 + lane;
+                const size_t wtap = (size_t)(k.cin_pad >> 1) * k.ntiles * 64;
+                for (int tap = 0; tap < ks * ks; ++tap) {
+                    const int toff = ((tap / ks) * HWt + (tap % ks)) * LDS_STRIDE;
+                    const float* wt = wc + tap * wtap;
 #pragma unroll 4
-                for (int kk = 0; kk < CK / 2; ++kk) {
-                    float av[MI];
+                    for (int kk = 0; kk < CK / 2; ++kk) {
+                        float av[MI];
 #pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) av[mi] = halo[base[mi] + toff + 2 * kk];
+                        for (int mi = 0; mi < MI; ++mi) av[mi] = halo[base[mi] + toff + 2 * kk];
 #pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) {
-                        const float bv = wt[((size_t)kk * k.ntiles + ni) * 64];
+                        for (int ni = 0; ni < NI; ++ni) {
+                            const float bv = wt[((size_t)kk * k.ntiles + ni) * 64];
 #pragma unroll
-                        for (int mi = 0; mi < MI; ++mi)
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv, acc[mi][ni], 0, 0, 0);
+                            for (int mi = 0; mi < MI; ++mi)
+                                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv, acc[mi][ni], 0, 0, 0);
+                        }
+                    }
+                }
+            } else {
+                // ---- taps x 2 k-steps x {hi*hi, lo*hi, hi*lo} of v_mfma_f32_32x32x16_f16 ----
+                // B fragments: [tap][cin_pad/16][ntiles][hi|lo][64 lanes][8 halfs], one coalesced 1 KiB load each
+                const f16x8* wc = reinterpret_cast<const f16x8*>(a.w) + ((size_t)(c0 >> 4) * k.ntiles + nt0) * 128 + lane;
+                const size_t wtap = (size_t)(k.cin_pad >> 4) * k.ntiles * 128;
+                for (int tap = 0; tap < ks * ks; ++tap) {
+                    const int toff = ((tap / ks) * HWt + (tap % ks)) * PIXB;
+                    const f16x8* wt = wc + tap * wtap;
+#pragma unroll
+                    for (int kk = 0; kk < CK / 16; ++kk) {
+                        f16x8 ah[MI], al[MI];
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi) {
+                            const char* p = halo_b + base[mi] + toff + kk * 32;
+                            ah[mi] = *reinterpret_cast<const f16x8*>(p);
+                            al[mi] = *reinterpret_cast<const f16x8*>(p + 64);
+                        }
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) {
+                            const f16x8 bh = wt[((size_t)kk * k.ntiles + ni) * 128];
+                            const f16x8 bl = wt[((size_t)kk * k.ntiles + ni) * 128 + 64];
+#pragma unroll
+                            for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh, acc[mi][ni], 0, 0, 0);
+#pragma unroll
+                            for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl, acc[mi][ni], 0, 0, 0);
+#pragma unroll
+                            for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh, acc[mi][ni], 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -159,9 +214,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_conv_f32(const ConvK k) {
         for (int ni = 0; ni < NI; ++ni) {
             const int co = (nt0 + ni) * 32 + (lane & 31);
             const bool cv = co < a.Cout;
-            float add = 0.f;
+            float add = 0.f, wsc = 1.0f;
             if (cv) {
                 add = a.bias ? a.bias[co] : 0.f;
+                if (PREC != CCDM_PREC_F32) wsc = k.wscale[co];        // exact power of two (per-channel weight pre-scale)
             }
             float embv = 0.f;
             const bool has_emb = a.emb_off >= 0 && cv;
@@ -174,7 +230,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_conv_f32(const ConvK k) {
                     const int oy = oy0 + p / TW, ox = ox0 + p % TW;
                     if (cv && oy < a.Hout && ox < a.Wout) {
                         const size_t idx = ((size_t)(n * a.Hout + oy) * a.Wout + ox) * a.Cout + co;
-                        float v = acc[mi][ni][r] + add;
+                        float v = (PREC == CCDM_PREC_F32 ? acc[mi][ni][r] : acc[mi][ni][r] * wsc) + add;
                         if (has_emb) v += embv;
                         if (a.resid) v += a.resid[idx];
                         a.out[idx] = v;
@@ -216,23 +272,39 @@ __global__ __launch_bounds__(WAVES * 64) void k_conv_f32(const ConvK k) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-template <int TH, int TW, int WAVES, int MI>
+template <int PREC, int TH, int TW, int WAVES, int MI>
 static int launch_geo(const ConvK& k, int NI, dim3 grid, size_t lds, hipStream_t s) {
     dim3 block(WAVES * 64);
     switch (NI) {
-        case 1: hipLaunchKernelGGL((k_conv_f32<TH, TW, WAVES, MI, 1>), grid, block, lds, s, k); break;
-        case 2: hipLaunchKernelGGL((k_conv_f32<TH, TW, WAVES, MI, 2>), grid, block, lds, s, k); break;
-        case 3: hipLaunchKernelGGL((k_conv_f32<TH, TW, WAVES, MI, 3>), grid, block, lds, s, k); break;
-        case 4: hipLaunchKernelGGL((k_conv_f32<TH, TW, WAVES, MI, 4>), grid, block, lds, s, k); break;
+        case 1: hipLaunchKernelGGL((k_conv<PREC, TH, TW, WAVES, MI, 1>), grid, block, lds, s, k); break;
+        case 2: hipLaunchKernelGGL((k_conv<PREC, TH, TW, WAVES, MI, 2>), grid, block, lds, s, k); break;
+        case 3: hipLaunchKernelGGL((k_conv<PREC, TH, TW, WAVES, MI, 3>), grid, block, lds, s, k); break;
+        case 4: hipLaunchKernelGGL((k_conv<PREC, TH, TW, WAVES, MI, 4>), grid, block, lds, s, k); break;
         default: return fail("conv: bad NI %d", NI);
     }
     return 0;
+}
+
+template <int PREC>
+static int launch_prec(const ConvK& k, const ConvGeo& g, int NI, dim3 grid, size_t lds, hipStream_t s) {
+    if (g.TW == 32) return launch_geo<PREC, 8, 32, 4, 2>(k, NI, grid, lds, s);
+    if (g.TW == 16) return launch_geo<PREC, 8, 16, 4, 1>(k, NI, grid, lds, s);
+    return launch_geo<PREC, 8, 8, 2, 1>(k, NI, grid, lds, s);
 }
 
 int conv_slices(int Hout, int Wout, int stride) {
     const ConvGeo g = conv_geo(Hout, Wout, stride);
     const int tiles = cdiv(Hout, g.TH) * cdiv(Wout, g.TW);
     return tiles < CCDM_STATS_MAX_SLICES ? tiles : CCDM_STATS_MAX_SLICES;
+}
+
+// bytes of the packed B fragments (the F16X3 per-channel scale table follows them)
+static size_t packed_frag_bytes(int Cout, int Cin, int ksize, int prec) {
+    int ntiles, NI;
+    conv_ntiles(Cout, &ntiles, &NI);
+    const size_t cin_pad = conv_cin_pad(Cin), taps = (size_t)ksize * ksize;
+    if (prec == CCDM_PREC_F32) return taps * (cin_pad / 2) * ntiles * 64 * sizeof(float);
+    return taps * (cin_pad / 16) * ntiles * 2 * 64 * 16;
 }
 
 int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
@@ -242,7 +314,7 @@ int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
     CCDM_REQUIRE(a.stride == 1 || a.stride == 2, "conv: stride %d", a.stride);
     CCDM_REQUIRE(a.C0 % 4 == 0 && a.C1 % 4 == 0 && C > 0, "conv: C0=%d C1=%d must be multiples of 4", a.C0, a.C1);
     CCDM_REQUIRE((a.C1 == 0) == (a.in1 == nullptr), "conv: in1/C1 mismatch");
-    CCDM_REQUIRE(a.prec == CCDM_PREC_F32, "conv: precision %d not built", a.prec);
+    CCDM_REQUIRE(a.prec == CCDM_PREC_F32 || a.prec == CCDM_PREC_F16X3, "conv: precision %d not built", a.prec);
     if (a.stats0) {
         CCDM_REQUIRE(C % 32 == 0, "conv: GroupNorm(32, %d) needs C %% 32 == 0", C);
         CCDM_REQUIRE(C <= CCDM_MAX_CHANNELS, "conv: %d input channels > CCDM_MAX_CHANNELS", C);
@@ -262,21 +334,22 @@ int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
     int NI;
     conv_ntiles(a.Cout, &k.ntiles, &NI);
     const ConvGeo g = conv_geo(a.Hout, a.Wout, a.stride);
+    // small spatial stages have few pixel tiles: spread the output-channel tiles over blocks instead
+    if (g.TW < 32) NI = 1;
     k.tiles_x = cdiv(a.Wout, g.TW);
     k.tiles_y = cdiv(a.Hout, g.TH);
     k.slices = conv_slices(a.Hout, a.Wout, a.stride);
+    k.wscale = reinterpret_cast<const float*>(static_cast<const char*>(a.w) + packed_frag_bytes(a.Cout, C, a.ksize, a.prec));
     if (a.out_stats) CCDM_REQUIRE(a.out_slices == k.slices, "conv: out_slices %d != %d", a.out_slices, k.slices);
     const int HP = ((g.TH - 1) * a.stride + a.ksize) * ((g.TW - 1) * a.stride + a.ksize);
-    size_t lds = (size_t)HP * LDS_STRIDE * 4;
+    size_t lds = (size_t)HP * (a.prec == CCDM_PREC_F32 ? LDS_STRIDE * 4 : LDS_PIX_BYTES_F16);
     const size_t red = (size_t)g.waves * NI * 32 * 16;
     if (lds < red) lds = red;
     if (a.stats0) lds += (size_t)C * 8;
     CCDM_REQUIRE(lds <= 160 * 1024, "conv: LDS %zu too large", lds);
     dim3 grid(a.N * k.slices, k.ntiles / NI);
-    int rc;
-    if (g.TW == 32) rc = launch_geo<8, 32, 4, 2>(k, NI, grid, lds, s);
-    else if (g.TW == 16) rc = launch_geo<8, 16, 4, 1>(k, NI, grid, lds, s);
-    else rc = launch_geo<8, 8, 2, 1>(k, NI, grid, lds, s);
+    const int rc = a.prec == CCDM_PREC_F32 ? launch_prec<CCDM_PREC_F32>(k, g, NI, grid, lds, s)
+                                           : launch_prec<CCDM_PREC_F16X3>(k, g, NI, grid, lds, s);
     if (rc) return rc;
     CCDM_CHECK_LAUNCH("conv");
     return 0;
@@ -294,25 +367,63 @@ extern "C" int ccdm_conv2d(const ccdm_conv_args* a, void* stream) {
     return ccdm::launch_conv(*a, (hipStream_t)stream);
 }
 
-// Packed layout (CCDM_PREC_F32): [tap][cin_pad/2][ntiles][64] floats; lane l of a (tap, k-pair, n-tile)
-// group holds W[cout = nt*32 + (l&31)][cin = 2*kp + (l>>5)][tap] — exactly the B fragment of
-// v_mfma_f32_32x32x2_f32, so a wave fetches it with one coalesced 256-byte load.
+// Packed layouts — the B operand exactly as the MFMA wants it, so a wave fetches a fragment with one
+// coalesced load:
+//  CCDM_PREC_F32:   [tap][cin_pad/2][ntiles][64] floats; lane l holds W[cout = nt*32 + (l&31)][cin = 2*kp + (l>>5)][tap]
+//                   (v_mfma_f32_32x32x2_f32).
+//  CCDM_PREC_F16X3: [tap][cin_pad/16][ntiles][hi|lo][64][8] halfs; lane l, element j holds
+//                   W[cout = nt*32 + (l&31)][cin = 16*ks + 8*(l>>5) + j][tap] * 2^e(cout), split into fp16
+//                   hi + lo (v_mfma_f32_32x32x16_f16), followed by [ntiles*32] floats 2^-e(cout).  The
+//                   per-output-channel power of two puts max|W| of the channel at ~2^10 so hi and lo both
+//                   sit in fp16's normal range; it is exact and undone exactly in the epilogue.
 extern "C" size_t ccdm_pack_conv_weight(const float* oihw, int Cout, int Cin, int ksize, int prec, void* out) {
-    if (prec != CCDM_PREC_F32) { ccdm::fail("pack: precision %d not built", prec); return 0; }
+    if (prec != CCDM_PREC_F32 && prec != CCDM_PREC_F16X3) { ccdm::fail("pack: precision %d not built", prec); return 0; }
     int ntiles, NI;
     ccdm::conv_ntiles(Cout, &ntiles, &NI);
     const int cin_pad = ccdm::conv_cin_pad(Cin), taps = ksize * ksize;
-    const size_t n = (size_t)taps * (cin_pad / 2) * ntiles * 64;
-    if (!out) return n * sizeof(float);
-    float* o = static_cast<float*>(out);
+    const size_t frag = ccdm::packed_frag_bytes(Cout, Cin, ksize, prec);
+    const size_t total = frag + (prec == CCDM_PREC_F16X3 ? (size_t)ntiles * 32 * sizeof(float) : 0);
+    if (!out) return total;
+    if (prec == CCDM_PREC_F32) {
+        float* o = static_cast<float*>(out);
+        for (int tap = 0; tap < taps; ++tap)
+            for (int kp = 0; kp < cin_pad / 2; ++kp)
+                for (int nt = 0; nt < ntiles; ++nt)
+                    for (int l = 0; l < 64; ++l) {
+                        const int co = nt * 32 + (l & 31), ci = 2 * kp + (l >> 5);
+                        float v = 0.f;
+                        if (co < Cout && ci < Cin) v = oihw[((size_t)co * Cin + ci) * taps + tap];
+                        o[(((size_t)tap * (cin_pad / 2) + kp) * ntiles + nt) * 64 + l] = v;
+                    }
+        return total;
+    }
+    _Float16* o = static_cast<_Float16*>(out);
+    float* sc = reinterpret_cast<float*>(static_cast<char*>(out) + frag);
+    std::vector<float> mul(ntiles * 32, 1.0f);
+    for (int co = 0; co < ntiles * 32; ++co) {
+        float mx = 0.f;
+        if (co < Cout)
+            for (size_t i = 0; i < (size_t)Cin * taps; ++i) mx = fmaxf(mx, fabsf(oihw[(size_t)co * Cin * taps + i]));
+        int e = 0;
+        if (mx > 0.f && std::isfinite(mx)) { int ex; frexpf(mx, &ex); e = 10 - ex; }     // mx*2^e in [2^9, 2^10)
+        if (e > 60) e = 60;
+        if (e < -60) e = -60;
+        mul[co] = ldexpf(1.0f, e);
+        sc[co] = ldexpf(1.0f, -e);
+    }
     for (int tap = 0; tap < taps; ++tap)
-        for (int kp = 0; kp < cin_pad / 2; ++kp)
+        for (int ks = 0; ks < cin_pad / 16; ++ks)
             for (int nt = 0; nt < ntiles; ++nt)
-                for (int l = 0; l < 64; ++l) {
-                    const int co = nt * 32 + (l & 31), ci = 2 * kp + (l >> 5);
-                    float v = 0.f;
-                    if (co < Cout && ci < Cin) v = oihw[((size_t)co * Cin + ci) * taps + tap];
-                    o[(((size_t)tap * (cin_pad / 2) + kp) * ntiles + nt) * 64 + l] = v;
-                }
-    return n * sizeof(float);
+                for (int l = 0; l < 64; ++l)
+                    for (int j = 0; j < 8; ++j) {
+                        const int co = nt * 32 + (l & 31), ci = 16 * ks + 8 * (l >> 5) + j;
+                        float v = 0.f;
+                        if (co < Cout && ci < Cin) v = oihw[((size_t)co * Cin + ci) * taps + tap] * mul[co];
+                        const _Float16 hi = (_Float16)v;
+                        const _Float16 lo = (_Float16)(v - (float)hi);
+                        const size_t base = ((((size_t)tap * (cin_pad / 16) + ks) * ntiles + nt) * 2) * 64 * 8;
+                        o[base + (size_t)l * 8 + j] = hi;
+                        o[base + 64 * 8 + (size_t)l * 8 + j] = lo;
+                    }
+    return total;
 }

@@ -70,8 +70,13 @@ CONV_CASES = [
 ]
 
 
+PRECS = [hip.PREC_F32, hip.PREC_F16X3]
+PREC_IDS = ["f32", "f16x3"]
+
+
+@pytest.mark.parametrize("prec", PRECS, ids=PREC_IDS)
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "-".join(map(str, c)))
-def test_conv(U, case):
+def test_conv(U, case, prec):
     c0, c1, cout, H, W, k, stride, up, gn, act, emb, resid = case
     rng = np.random.default_rng(sum(case))
     N = 2
@@ -103,7 +108,7 @@ def test_conv(U, case):
     out, ost = U.conv2d(srcs, w.numpy(), b.numpy(), k, stats=stats, gamma=gamma.numpy(), beta=beta.numpy(),
                         act=hip.ACT_SILU if act else hip.ACT_NONE, stride=stride, up=bool(up),
                         emb=embt.numpy() if emb else None, emb_rows=np.arange(N) if emb else None,
-                        resid=U.nhwc(res) if resid else None)
+                        resid=U.nhwc(res) if resid else None, prec=prec)
     got = U.bchw(out)
     np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=0, atol=2e-5)
     # fused output statistics == statistics of what was stored
@@ -130,11 +135,11 @@ def test_attention_core(U, C, T, order):
     qkv = rnd(rng, 2, 3 * C, T) * 1.3
     ref = (O.qkv_attention_new if order else O.qkv_attention_legacy)(qkv, heads)        # [N, C, T]
     got = U.attention(qkv.permute(0, 2, 1).contiguous().to(U.DEV), heads, order).cpu().permute(0, 2, 1)
-    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=0, atol=3e-6)
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=0, atol=1e-5)
 
 
 # ------------------------------------------------------------------------------------------ blocks (goldens)
-def _run_block(U, kind, kw, sd, x, emb):
+def _run_block(U, kind, kw, sd, x, emb, prec):
     xs = U.nhwc(x)
     st = U.gn_stats(xs, 1)
     p = "b."
@@ -144,35 +149,36 @@ def _run_block(U, kind, kw, sd, x, emb):
         film = kw["film"]
         h, hst = U.conv2d([xs], sd[p + "in_layers.2.weight"].numpy(), sd[p + "in_layers.2.bias"].numpy(), 3, stats=[st],
                           gamma=sd[p + "in_layers.0.weight"].numpy(), beta=sd[p + "in_layers.0.bias"].numpy(), act=hip.ACT_SILU,
-                          emb=None if film else e.numpy(), emb_rows=np.arange(N))
+                          emb=None if film else e.numpy(), emb_rows=np.arange(N), prec=prec)
         skip = xs
         if (p + "skip_connection.weight") in sd:
-            skip, _ = U.conv2d([xs], sd[p + "skip_connection.weight"].numpy(), sd[p + "skip_connection.bias"].numpy(), 1, want_stats=False)
+            skip, _ = U.conv2d([xs], sd[p + "skip_connection.weight"].numpy(), sd[p + "skip_connection.bias"].numpy(), 1, want_stats=False, prec=prec)
         y, _ = U.conv2d([h], sd[p + "out_layers.3.weight"].numpy(), sd[p + "out_layers.3.bias"].numpy(), 3, stats=[hst],
                         gamma=sd[p + "out_layers.0.weight"].numpy(), beta=sd[p + "out_layers.0.bias"].numpy(), act=hip.ACT_SILU,
-                        film=e.numpy() if film else None, emb_rows=np.arange(N), resid=skip)
+                        film=e.numpy() if film else None, emb_rows=np.arange(N), resid=skip, prec=prec)
         return U.bchw(y)
     if kind == "attn":
         C_ = kw["ch"]
         qkv, _ = U.conv2d([xs], sd[p + "qkv.weight"].numpy(), sd[p + "qkv.bias"].numpy(), 1, stats=[st],
-                          gamma=sd[p + "norm.weight"].numpy(), beta=sd[p + "norm.bias"].numpy(), want_stats=False)
+                          gamma=sd[p + "norm.weight"].numpy(), beta=sd[p + "norm.bias"].numpy(), want_stats=False, prec=prec)
         N, H, W, _ = qkv.shape
         a = U.attention(qkv.reshape(N, H * W, 3 * C_), C_ // 32, 1 if kw["new"] else 0).reshape(N, H, W, C_)
-        y, _ = U.conv2d([a], sd[p + "proj_out.weight"].numpy(), sd[p + "proj_out.bias"].numpy(), 1, resid=xs)
+        y, _ = U.conv2d([a], sd[p + "proj_out.weight"].numpy(), sd[p + "proj_out.bias"].numpy(), 1, resid=xs, prec=prec)
         return U.bchw(y)
     if kind == "down":
-        y, _ = U.conv2d([xs], sd[p + "op.weight"].numpy(), sd[p + "op.bias"].numpy(), 3, stride=2)
+        y, _ = U.conv2d([xs], sd[p + "op.weight"].numpy(), sd[p + "op.bias"].numpy(), 3, stride=2, prec=prec)
         return U.bchw(y)
-    y, _ = U.conv2d([xs], sd[p + "conv.weight"].numpy(), sd[p + "conv.bias"].numpy(), 3, up=True)
+    y, _ = U.conv2d([xs], sd[p + "conv.weight"].numpy(), sd[p + "conv.bias"].numpy(), 3, up=True, prec=prec)
     return U.bchw(y)
 
 
+@pytest.mark.parametrize("prec", PRECS, ids=PREC_IDS)
 @pytest.mark.parametrize("tag", list(BLOCK_CASES))
-def test_blocks_vs_reference_golden(U, golden, tag):
+def test_blocks_vs_reference_golden(U, golden, tag, prec):
     kind, kw, xs, seed = BLOCK_CASES[tag]
     w, x, emb = block_tensors(seed, golden.meta["block_shapes"][tag], xs)
     sd = {"b." + k: torch.from_numpy(v) for k, v in w.items()}
-    y = _run_block(U, kind, kw, sd, torch.from_numpy(x), torch.from_numpy(emb))
+    y = _run_block(U, kind, kw, sd, torch.from_numpy(x), torch.from_numpy(emb), prec)
     np.testing.assert_allclose(y.numpy(), golden["g3_blocks"][tag + ".y"], rtol=0, atol=3e-5)
 
 
@@ -286,12 +292,13 @@ def test_philox_stream_matches_oracle(U):
 
 
 # ------------------------------------------------------------------------------------------ whole network
-@pytest.fixture(scope="module")
-def lidc_model():
+@pytest.fixture(scope="module", params=PRECS, ids=PREC_IDS)
+def lidc_model(request):
     model = build_model(250, "cosine", {"s": 0.008}, [(1, 128, 128), (2, 128, 128)], (1, 128, 128), "unet_openai", LIDC_BP,
                         "datasets.lidc", "confidence", None)
     sd = {k: torch.from_numpy(v) for k, v in make_synthetic_state_dict(model.unet.spec, 0).items()}
     model.unet.load_state_dict(sd, strict=True)
+    model.prec = request.param
     return model.to("cuda:0").eval(), sd
 
 
@@ -375,7 +382,8 @@ def test_caller_contract_g9(U, golden, lidc_model):
     assert np.median(err) < 1e-5 and (err > 1e-3).mean() < 0.02
 
 
-def test_dino_concat_step_g8(U, golden):
+@pytest.mark.parametrize("prec", PRECS, ids=PREC_IDS)
+def test_dino_concat_step_g8(U, golden, prec):
     g = golden["g8_unet_step_dino"]
     fce = dict(type="dino", channels=384, output_stride=8, scale="single", target_layer=10)
     model = build_model(250, "cosine", None, [(3, 64, 128), (20, 64, 128)], (3, 64, 128), "unet_openai",
@@ -383,6 +391,7 @@ def test_dino_concat_step_g8(U, golden):
     sd = {k: torch.from_numpy(v) for k, v in make_synthetic_state_dict(model.unet.spec, 8).items()}
     model.unet.load_state_dict(sd, strict=True)
     model = model.to("cuda:0").eval()
+    model.prec = prec
     rng = np.random.default_rng(8)
     img = torch.from_numpy(rng.standard_normal((1, 3, 64, 128)).astype(np.float32))
     feat = torch.from_numpy(rng.standard_normal((1, 384, 8, 16)).astype(np.float32))
@@ -391,7 +400,7 @@ def test_dino_concat_step_g8(U, golden):
     err = np.abs(out.cpu().numpy() - g["out"])
     print("dino step max|dp| =", err.max())
     assert err.max() < 1e-4
-    with pytest.raises(ValueError, match="feature_condition is required"):
+    with pytest.raises(ValueError, match="feature"):
         model(O.one_hot_bchw(idx, 20).to(U.DEV), img.to(U.DEV), None, t=torch.full((1,), 120.0), validation=True)
 
 
