@@ -2,14 +2,22 @@
 // on NHWC fp32, implicit GEMM on the gfx950 matrix cores.
 //
 //   GEMM view:  M = output pixels (32-pixel sub-tiles of a TH x TW tile), N = output channels (32-wide
-//   tiles), K = taps x input channels, walked in chunks of 32 input channels.  Per chunk the block stages
+//   tiles), K = taps x input channels, walked in chunks of CK input channels.  Per chunk the block stages
 //   the (TH-1)*stride+k halo tile into LDS *already normalised and activated* (GroupNorm's affine is folded
 //   to one fma per element from per-channel partial sums the producer left behind), then every tap re-reads
 //   it from LDS: each input element is fetched from HBM once per tile, transformed once, used k*k*Cout times.
 //
-//   A block owns one (sample, slice) pair and loops over that slice's tiles, so it can leave its
-//   per-channel (sum, sum^2) partials for the *next* GroupNorm in a fixed slot — no atomics, fixed order,
-//   run-to-run deterministic.
+//   Pipeline per block (one (sample, slice) pair, looping over that slice's tiles x channel chunks):
+//       issue(i+1): global -> registers      (raw fp32, in flight during the MFMA phase of step i)
+//       barrier ; commit(i): registers -> GN affine -> SiLU -> [fp16 hi|lo split] -> LDS ; barrier
+//       MFMA phase(i): A and B fragments from LDS only — no vector-memory op between issue and the next
+//       commit, so the prefetch is never dragged in early by the in-order vmcnt queue.  (F16X3; the exact
+//       F32 path reads its pre-packed B fragments straight from L2.)
+//   HBM latency is paid once per tile-chunk and hidden behind the matrix phase; every geometry constant
+//   (halo width, item counts, tap offsets) is compile-time.
+//
+//   A block leaves its per-channel (sum, sum^2) partials for the *next* GroupNorm in a fixed slot —
+//   no atomics, fixed order, run-to-run deterministic, independent of the batch size.
 //
 // Replaces (reference, /root/reference/ddpm/models/unet_openai/unet.py): ResBlock in/out layers :186-219,
 // :242-262; skip 1x1 :221-228; Downsample :137-146; Upsample :106-116; AttentionBlock norm+qkv / proj_out
@@ -21,15 +29,18 @@
 
 namespace ccdm {
 
-static constexpr int CK = 32;          // input channels per K-chunk
-static constexpr int LDS_STRIDE = 33;  // F32: floats per halo pixel (odd: conflict-free column reads)
-// F16X3: bytes per halo pixel = 32 hi halfs | 32 lo halfs | 16 pad.  144 B = 36 dwords: the 16 pixels of a
-// ds_read_b128 lane group land on 16 disjoint 4-bank slots (36*p mod 64 is a permutation of multiples of 4).
-static constexpr int LDS_PIX_BYTES_F16 = 144;
+// F32  : CK = 32 channels per chunk; LDS pixel = 33 floats (odd stride: conflict-free column reads).
+// F16X3: CK = 16 channels per chunk; LDS pixel = 16 hi halfs | 16 lo halfs | 16 B pad = 80 B = 20 dwords:
+//        the 16 pixels of a ds_read_b128 lane group land on 16 disjoint 4-bank slots (20*p mod 64).
+template <int PREC> struct Lds {
+    static constexpr int CK = PREC == CCDM_PREC_F32 ? 32 : 16;
+    static constexpr int PIXB = PREC == CCDM_PREC_F32 ? 33 * 4 : 80;
+};
 
-__device__ __forceinline__ int pix_bytes(int prec) { return prec == CCDM_PREC_F32 ? LDS_STRIDE * 4 : LDS_PIX_BYTES_F16; }
-
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float silu_fast(float x) {
+    // x * sigmoid(x) with v_exp_f32 / v_rcp_f32 (1 ulp each); limits: x -> -inf gives -0, x -> +inf gives x
+    return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+}
 
 struct ConvK {   // kernel-side copy of ccdm_conv_args (+ derived)
     ccdm_conv_args a;
@@ -74,168 +85,251 @@ __device__ __forceinline__ void compute_gn_affine(const ccdm_conv_args& a, int n
     }
 }
 
-template <int PREC, int TH, int TW, int WAVES, int MI, int NI>
-__global__ __launch_bounds__(WAVES * 64) void k_conv(const ConvK k) {
+// register budget: >= 3 waves per SIMD (<= 168 VGPRs) when the accumulator tile is small — matches the 3 blocks
+// per CU the LDS footprint (A tile 27 KB + B chunk 18 KB) admits
+constexpr int min_waves(int mi, int ni) { return mi * ni <= 2 ? 3 : (mi * ni <= 4 ? 2 : 1); }
+
+template <int PREC, int KS, int STRIDE, int TH, int TW, int WAVES, int MI, int NI>
+__global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI)) void k_conv(const ConvK k) {
+    constexpr int NT = WAVES * 64;
+    constexpr int CK = Lds<PREC>::CK, PIXB = Lds<PREC>::PIXB;
+    constexpr int PAD = KS / 2;
+    constexpr int HHt = (TH - 1) * STRIDE + KS, HWt = (TW - 1) * STRIDE + KS, HP = HHt * HWt;
+    constexpr int QPP = CK / 4;                                   // float4 items per halo pixel
+    constexpr int NITEM = (HP * QPP + NT - 1) / NT;               // staging items per thread
+    static_assert(NITEM <= 32, "validity mask is 32 bits");
+    constexpr int A_BYTES = (HP * PIXB + 15) / 16 * 16;
+    // F16X3: the chunk's B fragments, [tap][ni][hi|lo][64 lanes] x 16 B, staged through registers like the halo
+    constexpr int NB4 = PREC == CCDM_PREC_F32 ? 0 : KS * KS * NI * 128;
+    constexpr int NITEM_B = (NB4 + NT - 1) / NT;
+
     const ccdm_conv_args& a = k.a;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int C = a.C0 + a.C1;
     float2* ab = reinterpret_cast<float2*>(smem);                              // [C] (only if stats0)
     char* halo_b = smem + (a.stats0 ? (size_t)C * 8 : 0);
     float* halo = reinterpret_cast<float*>(halo_b);
-    constexpr int PIXB = PREC == CCDM_PREC_F32 ? LDS_STRIDE * 4 : LDS_PIX_BYTES_F16;
+    f32x4* ldsB = reinterpret_cast<f32x4*>(halo_b + A_BYTES);      // native vector type: HIP's float4 struct defeats SROA here
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n = blockIdx.x / k.slices, slice = blockIdx.x % k.slices;
+    // XCD-aware mapping: block b runs on XCD b % 8 — give each XCD a contiguous range of (sample, slice)
+    // pairs so the slices of a sample (shared halo rows, shared statistics) meet in one L2.
+    int bid = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int n = bid / k.slices, slice = bid % k.slices;
     const int nt0 = blockIdx.y * NI;
-    const int ks = a.ksize, pad = ks >> 1, stride = a.stride;
-    const int HHt = (TH - 1) * stride + ks, HWt = (TW - 1) * stride + ks, HP = HHt * HWt;
     const int Hc = a.up ? a.Hin * 2 : a.Hin, Wc = a.up ? a.Win * 2 : a.Win;    // conv-input space
     const int step = a.step_ptr ? *a.step_ptr : 0;
     const int emb_row = (a.emb_row_of_sample ? a.emb_row_of_sample[n] : 0) + step;
+    const bool has_gn = a.stats0 != nullptr;
 
-    if (a.stats0) compute_gn_affine(a, n, emb_row, ab);
+    if (has_gn) compute_gn_affine(a, n, emb_row, ab);
 
-    // per-lane LDS base of each of this wave's 32-pixel sub-tiles (A operand: row = lane&31, k = lane>>5)
+    // per-lane LDS base of each of this wave's 32-pixel sub-tiles (A operand: row = lane&31, k-group = lane>>5)
     int base[MI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int p = (wave * MI + mi) * 32 + (lane & 31);
-        if (PREC == CCDM_PREC_F32) base[mi] = ((p / TW) * stride * HWt + (p % TW) * stride) * LDS_STRIDE + (lane >> 5);
-        else base[mi] = ((p / TW) * stride * HWt + (p % TW) * stride) * PIXB + (lane >> 5) * 16;     // bytes
+        const int hpix = (p / TW) * STRIDE * HWt + (p % TW) * STRIDE;
+        base[mi] = PREC == CCDM_PREC_F32 ? hpix * 33 + (lane >> 5) : hpix * PIXB + (lane >> 5) * 16;   // floats | bytes
     }
     double s1[NI], s2[NI];
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) { s1[ni] = 0.0; s2[ni] = 0.0; }
 
     const int ntile_sp = k.tiles_x * k.tiles_y;
-    for (int tile = slice; tile < ntile_sp; tile += k.slices) {
-        const int oy0 = (tile / k.tiles_x) * TH, ox0 = (tile % k.tiles_x) * TW;
-        f32x16 acc[MI][NI];
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+    const int nchunk = k.cin_pad / CK;
+    const int my_tiles = (ntile_sp - slice + k.slices - 1) / k.slices;
+    const int n_iter = my_tiles * nchunk;
 
-        for (int c0 = 0; c0 < k.cin_pad; c0 += CK) {
-            __syncthreads();   // previous chunk's reads (and the affine table) are done / visible
-            // ---- stage the halo tile of channels [c0, c0+32), normalised + activated, zero padded ----
-            for (int item = tid; item < HP * (CK / 4); item += WAVES * 64) {
-                const int hp = item >> 3, q = item & 7;
-                const int hy = hp / HWt, hx = hp - hy * HWt;
-                const int iy = oy0 * stride - pad + hy, ix = ox0 * stride - pad + hx;
-                const int c = c0 + 4 * q;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (iy >= 0 && iy < Hc && ix >= 0 && ix < Wc && c < C) {
-                    const int sy = a.up ? (iy >> 1) : iy, sx = a.up ? (ix >> 1) : ix;
-                    const float* src; int cc, Cs;
-                    if (c < a.C0) { src = a.in0; cc = c; Cs = a.C0; }
-                    else { src = a.in1; cc = c - a.C0; Cs = a.C1; }
-                    v = *reinterpret_cast<const float4*>(src + ((size_t)(n * a.Hin + sy) * a.Win + sx) * Cs + cc);
-                    if (a.stats0) {
+    f32x4 reg[NITEM];
+    f32x4 regB[NITEM_B > 0 ? NITEM_B : 1];
+    unsigned valid = 0;
+
+    // ---- issue: global -> registers for iteration `it` (tile, chunk) ----
+    auto issue = [&](int it) {
+        const int tile = slice + (it / nchunk) * k.slices, c0 = (it % nchunk) * CK;
+        const int oy0 = (tile / k.tiles_x) * TH, ox0 = (tile % k.tiles_x) * TW;
+        valid = 0;
+        int t_ = tid;
+        asm volatile("" : "+v"(t_));     // recompute the item geometry each call: hoisting it costs more registers than ALU
+#pragma unroll
+        for (int i = 0; i < NITEM; ++i) {
+            const int item = t_ + i * NT;
+            const int hp = item / QPP, q = item % QPP;
+            const int hy = hp / HWt, hx = hp % HWt;                         // compile-time divisors
+            const int iy = oy0 * STRIDE - PAD + hy, ix = ox0 * STRIDE - PAD + hx;
+            const int c = c0 + 4 * q;
+            const bool ok = item < HP * QPP && iy >= 0 && iy < Hc && ix >= 0 && ix < Wc && c < C;
+            // branch-free: the load is always issued (address clamped into the tensor), padding is zeroed at commit.
+            // A conditional load would put a control-flow join between the prefetch and the MFMA phase, and the
+            // waitcnt pass then drains the whole prefetch (vmcnt(0)) at the join.
+            const int iyc = min(max(iy, 0), Hc - 1), ixc = min(max(ix, 0), Wc - 1), cq = min(c, C - 4);
+            const int sy = a.up ? (iyc >> 1) : iyc, sx = a.up ? (ixc >> 1) : ixc;
+            const bool first = cq < a.C0;
+            const float* src = first ? a.in0 : a.in1;
+            const int cc = first ? cq : cq - a.C0, Cs = first ? a.C0 : a.C1;
+            reg[i] = *reinterpret_cast<const f32x4*>(src + ((size_t)(n * a.Hin + sy) * a.Win + sx) * Cs + cc);
+            valid |= (ok ? 1u : 0u) << i;
+        }
+        if (PREC != CCDM_PREC_F32) {
+            const f32x4* wq = reinterpret_cast<const f32x4*>(a.w) + ((size_t)(c0 >> 4) * k.ntiles + nt0) * 128;
+            const size_t wtap = (size_t)(k.cin_pad >> 4) * k.ntiles * 128;
+#pragma unroll
+            for (int i = 0; i < NITEM_B; ++i) {
+                int j = t_ + i * NT;
+                j = j < NB4 ? j : NB4 - 1;            // unconditional load (keeps regB[] in registers)
+                regB[i] = wq[(size_t)(j / (NI * 128)) * wtap + (j % (NI * 128))];
+            }
+        }
+    };
+    // ---- commit: registers -> affine -> SiLU -> LDS (zero where padded) ----
+    auto commit = [&](int it) {
+        const int c0 = (it % nchunk) * CK;
+        int t_ = tid;
+        asm volatile("" : "+v"(t_));
+#pragma unroll
+        for (int i = 0; i < NITEM; ++i) {
+            const int item = t_ + i * NT;
+            if (item < HP * QPP) {
+                const int hp = item / QPP, q = item % QPP;
+                float4 v = make_float4(reg[i][0], reg[i][1], reg[i][2], reg[i][3]);
+                if (!((valid >> i) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                else {
+                    if (has_gn) {
+                        const int c = c0 + 4 * q;
                         const float2 t0 = ab[c], t1 = ab[c + 1], t2 = ab[c + 2], t3 = ab[c + 3];
                         v.x = fmaf(v.x, t0.x, t0.y); v.y = fmaf(v.y, t1.x, t1.y);
                         v.z = fmaf(v.z, t2.x, t2.y); v.w = fmaf(v.w, t3.x, t3.y);
                     }
-                    if (a.act == CCDM_ACT_SILU) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+                    if (a.act == CCDM_ACT_SILU) { v.x = silu_fast(v.x); v.y = silu_fast(v.y); v.z = silu_fast(v.z); v.w = silu_fast(v.w); }
                 }
                 if (PREC == CCDM_PREC_F32) {
-                    float* d = halo + hp * LDS_STRIDE + 4 * q;
+                    float* d = halo + hp * 33 + 4 * q;
                     d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
                 } else {
-                    // fp16 hi/lo split: x = hi + lo + O(2^-22 |x|); both halves rounded to nearest
+                    // fp16 hi/lo split: x = hi + lo + O(2^-22 |x|); both halves round-to-nearest
                     f16x4 hi, lo;
                     hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
                     lo[0] = (_Float16)(v.x - (float)hi[0]); lo[1] = (_Float16)(v.y - (float)hi[1]);
                     lo[2] = (_Float16)(v.z - (float)hi[2]); lo[3] = (_Float16)(v.w - (float)hi[3]);
                     char* d = halo_b + hp * PIXB + 8 * q;
                     *reinterpret_cast<f16x4*>(d) = hi;
-                    *reinterpret_cast<f16x4*>(d + 64) = lo;
-                }
-            }
-            __syncthreads();
-            if (PREC == CCDM_PREC_F32) {
-                // ---- taps x 16 k-steps of v_mfma_f32_32x32x2_f32 ----
-                const float* wc = reinterpret_cast<const float*>(a.w) + ((size_t)(c0 >> 1) * k.ntiles + nt0) * 64 + lane;
-                const size_t wtap = (size_t)(k.cin_pad >> 1) * k.ntiles * 64;
-                for (int tap = 0; tap < ks * ks; ++tap) {
-                    const int toff = ((tap / ks) * HWt + (tap % ks)) * LDS_STRIDE;
-                    const float* wt = wc + tap * wtap;
-#pragma unroll 4
-                    for (int kk = 0; kk < CK / 2; ++kk) {
-                        float av[MI];
-#pragma unroll
-                        for (int mi = 0; mi < MI; ++mi) av[mi] = halo[base[mi] + toff + 2 * kk];
-#pragma unroll
-                        for (int ni = 0; ni < NI; ++ni) {
-                            const float bv = wt[((size_t)kk * k.ntiles + ni) * 64];
-#pragma unroll
-                            for (int mi = 0; mi < MI; ++mi)
-                                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv, acc[mi][ni], 0, 0, 0);
-                        }
-                    }
-                }
-            } else {
-                // ---- taps x 2 k-steps x {hi*hi, lo*hi, hi*lo} of v_mfma_f32_32x32x16_f16 ----
-                // B fragments: [tap][cin_pad/16][ntiles][hi|lo][64 lanes][8 halfs], one coalesced 1 KiB load each
-                const f16x8* wc = reinterpret_cast<const f16x8*>(a.w) + ((size_t)(c0 >> 4) * k.ntiles + nt0) * 128 + lane;
-                const size_t wtap = (size_t)(k.cin_pad >> 4) * k.ntiles * 128;
-                for (int tap = 0; tap < ks * ks; ++tap) {
-                    const int toff = ((tap / ks) * HWt + (tap % ks)) * PIXB;
-                    const f16x8* wt = wc + tap * wtap;
-#pragma unroll
-                    for (int kk = 0; kk < CK / 16; ++kk) {
-                        f16x8 ah[MI], al[MI];
-#pragma unroll
-                        for (int mi = 0; mi < MI; ++mi) {
-                            const char* p = halo_b + base[mi] + toff + kk * 32;
-                            ah[mi] = *reinterpret_cast<const f16x8*>(p);
-                            al[mi] = *reinterpret_cast<const f16x8*>(p + 64);
-                        }
-#pragma unroll
-                        for (int ni = 0; ni < NI; ++ni) {
-                            const f16x8 bh = wt[((size_t)kk * k.ntiles + ni) * 128];
-                            const f16x8 bl = wt[((size_t)kk * k.ntiles + ni) * 128 + 64];
-#pragma unroll
-                            for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh, acc[mi][ni], 0, 0, 0);
-#pragma unroll
-                            for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl, acc[mi][ni], 0, 0, 0);
-#pragma unroll
-                            for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh, acc[mi][ni], 0, 0, 0);
-                        }
-                    }
+                    *reinterpret_cast<f16x4*>(d + 32) = lo;
                 }
             }
         }
-        // ---- epilogue: + bias (+ emb) (+ residual), store NHWC, accumulate output statistics ----
+        if (PREC != CCDM_PREC_F32) {
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            const int co = (nt0 + ni) * 32 + (lane & 31);
-            const bool cv = co < a.Cout;
-            float add = 0.f, wsc = 1.0f;
-            if (cv) {
-                add = a.bias ? a.bias[co] : 0.f;
-                if (PREC != CCDM_PREC_F32) wsc = k.wscale[co];        // exact power of two (per-channel weight pre-scale)
+            for (int i = 0; i < NITEM_B; ++i) {
+                const int j = t_ + i * NT;
+                if (j < NB4) ldsB[j] = regB[i];
             }
-            float embv = 0.f;
-            const bool has_emb = a.emb_off >= 0 && cv;
-            if (has_emb) embv = a.emb_table[(size_t)emb_row * a.emb_stride + a.emb_off + co];
+        }
+    };
+
+    f32x16 acc[MI][NI];
+    if (n_iter > 0) issue(0);
+    for (int it = 0; it < n_iter; ++it) {
+        const int chunk = it % nchunk;
+        if (chunk == 0) {
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int p = (wave * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    const int oy = oy0 + p / TW, ox = ox0 + p % TW;
-                    if (cv && oy < a.Hout && ox < a.Wout) {
-                        const size_t idx = ((size_t)(n * a.Hout + oy) * a.Wout + ox) * a.Cout + co;
-                        float v = (PREC == CCDM_PREC_F32 ? acc[mi][ni][r] : acc[mi][ni][r] * wsc) + add;
-                        if (has_emb) v += embv;
-                        if (a.resid) v += a.resid[idx];
-                        a.out[idx] = v;
-                        s1[ni] += (double)v;
-                        s2[ni] += (double)v * (double)v;
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+        }
+        __syncthreads();          // previous MFMA phase has finished reading LDS (and ab[] is visible)
+        commit(it);
+        __syncthreads();
+        issue(it + 1 < n_iter ? it + 1 : it);    // next tile-chunk's HBM reads fly during the MFMA phase (the last one re-reads its own: harmless, branch-free)
+
+        const int c0 = chunk * CK;
+        if (PREC == CCDM_PREC_F32) {
+            // taps x 16 k-steps of v_mfma_f32_32x32x2_f32; B: [tap][cin_pad/2][ntiles][64] floats
+            const float* wc = reinterpret_cast<const float*>(a.w) + ((size_t)(c0 >> 1) * k.ntiles + nt0) * 64 + lane;
+            const size_t wtap = (size_t)(k.cin_pad >> 1) * k.ntiles * 64;
+#pragma unroll
+            for (int tap = 0; tap < KS * KS; ++tap) {
+                const int toff = ((tap / KS) * HWt + (tap % KS)) * 33;
+                const float* wt = wc + tap * wtap;
+#pragma unroll 4
+                for (int kk = 0; kk < CK / 2; ++kk) {
+                    float av[MI];
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) av[mi] = halo[base[mi] + toff + 2 * kk];
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        const float bv = wt[((size_t)kk * k.ntiles + ni) * 64];
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv, acc[mi][ni], 0, 0, 0);
+                    }
+                }
+            }
+        } else {
+            // taps x {lo*hi, hi*lo, hi*hi} of v_mfma_f32_32x32x16_f16 (one 16-channel k-step per chunk);
+            // A: halo tile, B: [tap][ni][hi|lo][lane] fragments, both in LDS
+            const f16x8* bq = reinterpret_cast<const f16x8*>(ldsB) + lane;
+#pragma unroll
+            for (int tap = 0; tap < KS * KS; ++tap) {
+                const int toff = ((tap / KS) * HWt + (tap % KS)) * PIXB;
+                f16x8 ah[MI], al[MI];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const char* p = halo_b + base[mi] + toff;
+                    ah[mi] = *reinterpret_cast<const f16x8*>(p);
+                    al[mi] = *reinterpret_cast<const f16x8*>(p + 32);
+                }
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const f16x8 bh = bq[(tap * NI + ni) * 128];
+                    const f16x8 bl = bq[(tap * NI + ni) * 128 + 64];
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh, acc[mi][ni], 0, 0, 0);
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl, acc[mi][ni], 0, 0, 0);
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh, acc[mi][ni], 0, 0, 0);
+                }
+            }
+        }
+
+        if (chunk == nchunk - 1) {
+            // ---- epilogue: (x 2^-e) + bias (+ emb) (+ residual), store NHWC, accumulate output statistics ----
+            const int tile = slice + (it / nchunk) * k.slices;
+            const int oy0 = (tile / k.tiles_x) * TH, ox0 = (tile % k.tiles_x) * TW;
+            int lane_ = lane;
+            asm volatile("" : "+v"(lane_));
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int co = (nt0 + ni) * 32 + (lane_ & 31);
+                const bool cv = co < a.Cout;
+                float add = 0.f, wsc = 1.0f;
+                if (cv) {
+                    add = a.bias ? a.bias[co] : 0.f;
+                    if (PREC != CCDM_PREC_F32) wsc = k.wscale[co];        // exact power of two
+                }
+                float embv = 0.f;
+                const bool has_emb = a.emb_off >= 0 && cv;
+                if (has_emb) embv = a.emb_table[(size_t)emb_row * a.emb_stride + a.emb_off + co];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int p = (wave * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane_ >> 5);
+                        const int oy = oy0 + p / TW, ox = ox0 + p % TW;
+                        if (cv && oy < a.Hout && ox < a.Wout) {
+                            const size_t idx = ((size_t)(n * a.Hout + oy) * a.Wout + ox) * a.Cout + co;
+                            float v = (PREC == CCDM_PREC_F32 ? acc[mi][ni][r] : acc[mi][ni][r] * wsc) + add;
+                            if (has_emb) v += embv;
+                            if (a.resid) v += a.resid[idx];
+                            a.out[idx] = v;
+                            s1[ni] += (double)v;
+                            s2[ni] += (double)v * (double)v;
+                        }
                     }
                 }
             }
@@ -245,7 +339,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_conv(const ConvK k) {
     if (a.out_stats) {
         // lanes l and l+32 hold the same channel; then the block's waves; fixed order everywhere
         __syncthreads();
-        double* red = reinterpret_cast<double*>(halo);     // [WAVES][NI][32][2]
+        double* red = reinterpret_cast<double*>(halo_b);     // [WAVES][NI][32][2]
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             const double o1 = __shfl_xor(s1[ni], 32), o2 = __shfl_xor(s2[ni], 32);
@@ -255,7 +349,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_conv(const ConvK k) {
             }
         }
         __syncthreads();
-        for (int i = tid; i < NI * 32; i += WAVES * 64) {
+        for (int i = tid; i < NI * 32; i += NT) {
             const int ni = i >> 5, l = i & 31;
             double t1 = 0.0, t2 = 0.0;
             for (int w = 0; w < WAVES; ++w) {
@@ -272,37 +366,55 @@ __global__ __launch_bounds__(WAVES * 64) void k_conv(const ConvK k) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-template <int PREC, int TH, int TW, int WAVES, int MI>
-static int launch_geo(const ConvK& k, int NI, dim3 grid, size_t lds, hipStream_t s) {
+template <int PREC, int KS, int STRIDE, int TH, int TW, int WAVES, int MI>
+static int launch_ni(const ConvK& k, int NI, dim3 grid, size_t lds, hipStream_t s) {
     dim3 block(WAVES * 64);
     switch (NI) {
-        case 1: hipLaunchKernelGGL((k_conv<PREC, TH, TW, WAVES, MI, 1>), grid, block, lds, s, k); break;
-        case 2: hipLaunchKernelGGL((k_conv<PREC, TH, TW, WAVES, MI, 2>), grid, block, lds, s, k); break;
-        case 3: hipLaunchKernelGGL((k_conv<PREC, TH, TW, WAVES, MI, 3>), grid, block, lds, s, k); break;
-        case 4: hipLaunchKernelGGL((k_conv<PREC, TH, TW, WAVES, MI, 4>), grid, block, lds, s, k); break;
+        case 1: hipLaunchKernelGGL((k_conv<PREC, KS, STRIDE, TH, TW, WAVES, MI, 1>), grid, block, lds, s, k); break;
+        case 2: hipLaunchKernelGGL((k_conv<PREC, KS, STRIDE, TH, TW, WAVES, MI, 2>), grid, block, lds, s, k); break;
+        case 3: hipLaunchKernelGGL((k_conv<PREC, KS, STRIDE, TH, TW, WAVES, MI, 3>), grid, block, lds, s, k); break;
+        case 4: hipLaunchKernelGGL((k_conv<PREC, KS, STRIDE, TH, TW, WAVES, MI, 4>), grid, block, lds, s, k); break;
         default: return fail("conv: bad NI %d", NI);
     }
     return 0;
 }
 
+template <int PREC, int KS>
+static int launch_geo(const ConvK& k, const ConvGeo& g, int NI, dim3 grid, size_t lds, hipStream_t s) {
+    if (k.a.stride == 2) return launch_ni<PREC, KS, 2, 8, 8, 2, 1>(k, NI, grid, lds, s);
+    if (g.TW == 32) return launch_ni<PREC, KS, 1, 8, 32, 4, 2>(k, NI, grid, lds, s);
+    if (g.TW == 16) return launch_ni<PREC, KS, 1, 8, 16, 4, 1>(k, NI, grid, lds, s);
+    return launch_ni<PREC, KS, 1, 8, 8, 2, 1>(k, NI, grid, lds, s);
+}
+
 template <int PREC>
 static int launch_prec(const ConvK& k, const ConvGeo& g, int NI, dim3 grid, size_t lds, hipStream_t s) {
-    if (g.TW == 32) return launch_geo<PREC, 8, 32, 4, 2>(k, NI, grid, lds, s);
-    if (g.TW == 16) return launch_geo<PREC, 8, 16, 4, 1>(k, NI, grid, lds, s);
-    return launch_geo<PREC, 8, 8, 2, 1>(k, NI, grid, lds, s);
+#ifdef CCDM_EXPERIMENT   // compile one instantiation only (register/ISA experiments)
+    hipLaunchKernelGGL((k_conv<CCDM_PREC_F16X3, 3, 1, 8, 32, 4, 2, 1>), grid, dim3(256), lds, s, k);
+    return 0;
+#else
+    if (k.a.ksize == 3) return launch_geo<PREC, 3>(k, g, NI, grid, lds, s);
+    return launch_geo<PREC, 1>(k, g, NI, grid, lds, s);
+#endif
 }
 
 int conv_slices(int Hout, int Wout, int stride) {
     const ConvGeo g = conv_geo(Hout, Wout, stride);
     const int tiles = cdiv(Hout, g.TH) * cdiv(Wout, g.TW);
+    // 12 slices for big images: with 3 resident blocks per CU, 64 samples x 12 slices = 768 blocks fill the 256 CUs
+    // in exactly one round.  A function of the spatial size only (never of N): sharding the batch must not change
+    // the order in which statistics partials are added.
+    if (tiles >= 48) return 12;
     return tiles < CCDM_STATS_MAX_SLICES ? tiles : CCDM_STATS_MAX_SLICES;
 }
+
+static int cin_pad_for(int Cin, int prec) { return prec == CCDM_PREC_F32 ? cdiv(Cin, 32) * 32 : cdiv(Cin, 16) * 16; }
 
 // bytes of the packed B fragments (the F16X3 per-channel scale table follows them)
 static size_t packed_frag_bytes(int Cout, int Cin, int ksize, int prec) {
     int ntiles, NI;
     conv_ntiles(Cout, &ntiles, &NI);
-    const size_t cin_pad = conv_cin_pad(Cin), taps = (size_t)ksize * ksize;
+    const size_t cin_pad = cin_pad_for(Cin, prec), taps = (size_t)ksize * ksize;
     if (prec == CCDM_PREC_F32) return taps * (cin_pad / 2) * ntiles * 64 * sizeof(float);
     return taps * (cin_pad / 16) * ntiles * 2 * 64 * 16;
 }
@@ -312,6 +424,7 @@ int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
     CCDM_REQUIRE(a.in0 && a.out && a.w, "conv: null in0/out/w");
     CCDM_REQUIRE(a.ksize == 1 || a.ksize == 3, "conv: ksize %d (need 1 or 3)", a.ksize);
     CCDM_REQUIRE(a.stride == 1 || a.stride == 2, "conv: stride %d", a.stride);
+    CCDM_REQUIRE(a.stride == 1 || a.ksize == 3, "conv: stride 2 is built for 3x3 only");
     CCDM_REQUIRE(a.C0 % 4 == 0 && a.C1 % 4 == 0 && C > 0, "conv: C0=%d C1=%d must be multiples of 4", a.C0, a.C1);
     CCDM_REQUIRE((a.C1 == 0) == (a.in1 == nullptr), "conv: in1/C1 mismatch");
     CCDM_REQUIRE(a.prec == CCDM_PREC_F32 || a.prec == CCDM_PREC_F16X3, "conv: precision %d not built", a.prec);
@@ -330,19 +443,23 @@ int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
 
     ConvK k;
     k.a = a;
-    k.cin_pad = conv_cin_pad(C);
+    k.cin_pad = cin_pad_for(C, a.prec);
     int NI;
     conv_ntiles(a.Cout, &k.ntiles, &NI);
     const ConvGeo g = conv_geo(a.Hout, a.Wout, a.stride);
-    // small spatial stages have few pixel tiles: spread the output-channel tiles over blocks instead
+    // small spatial stages have few pixel tiles: spread the output-channel tiles over blocks instead;
+    // wide tiles take at most 2 n-tiles per block (register budget of the staged B chunk)
     if (g.TW < 32) NI = 1;
+    else NI = (k.ntiles % 2 == 0) ? 2 : 1;
     k.tiles_x = cdiv(a.Wout, g.TW);
     k.tiles_y = cdiv(a.Hout, g.TH);
     k.slices = conv_slices(a.Hout, a.Wout, a.stride);
     k.wscale = reinterpret_cast<const float*>(static_cast<const char*>(a.w) + packed_frag_bytes(a.Cout, C, a.ksize, a.prec));
     if (a.out_stats) CCDM_REQUIRE(a.out_slices == k.slices, "conv: out_slices %d != %d", a.out_slices, k.slices);
     const int HP = ((g.TH - 1) * a.stride + a.ksize) * ((g.TW - 1) * a.stride + a.ksize);
-    size_t lds = (size_t)HP * (a.prec == CCDM_PREC_F32 ? LDS_STRIDE * 4 : LDS_PIX_BYTES_F16);
+    size_t lds = (size_t)HP * (a.prec == CCDM_PREC_F32 ? Lds<CCDM_PREC_F32>::PIXB : Lds<CCDM_PREC_F16X3>::PIXB);
+    lds = (lds + 15) / 16 * 16;
+    if (a.prec != CCDM_PREC_F32) lds += (size_t)a.ksize * a.ksize * NI * 128 * 16;     // staged B chunk
     const size_t red = (size_t)g.waves * NI * 32 * 16;
     if (lds < red) lds = red;
     if (a.stats0) lds += (size_t)C * 8;
@@ -369,18 +486,18 @@ extern "C" int ccdm_conv2d(const ccdm_conv_args* a, void* stream) {
 
 // Packed layouts — the B operand exactly as the MFMA wants it, so a wave fetches a fragment with one
 // coalesced load:
-//  CCDM_PREC_F32:   [tap][cin_pad/2][ntiles][64] floats; lane l holds W[cout = nt*32 + (l&31)][cin = 2*kp + (l>>5)][tap]
-//                   (v_mfma_f32_32x32x2_f32).
-//  CCDM_PREC_F16X3: [tap][cin_pad/16][ntiles][hi|lo][64][8] halfs; lane l, element j holds
-//                   W[cout = nt*32 + (l&31)][cin = 16*ks + 8*(l>>5) + j][tap] * 2^e(cout), split into fp16
-//                   hi + lo (v_mfma_f32_32x32x16_f16), followed by [ntiles*32] floats 2^-e(cout).  The
-//                   per-output-channel power of two puts max|W| of the channel at ~2^10 so hi and lo both
-//                   sit in fp16's normal range; it is exact and undone exactly in the epilogue.
+//  CCDM_PREC_F32:   [tap][cin_pad/2][ntiles][64] floats (cin_pad = Cin rounded up to 32); lane l holds
+//                   W[cout = nt*32 + (l&31)][cin = 2*kp + (l>>5)][tap]      (v_mfma_f32_32x32x2_f32).
+//  CCDM_PREC_F16X3: [tap][cin_pad/16][ntiles][hi|lo][64][8] halfs (cin_pad = Cin rounded up to 16); lane l,
+//                   element j holds W[cout = nt*32 + (l&31)][cin = 16*ks + 8*(l>>5) + j][tap] * 2^e(cout), split
+//                   into fp16 hi + lo (v_mfma_f32_32x32x16_f16), followed by [ntiles*32] floats 2^-e(cout).
+//                   The per-output-channel power of two puts max|W| of the channel in [2^9, 2^10) so hi and lo
+//                   both sit in fp16's normal range; it is exact and undone exactly in the epilogue.
 extern "C" size_t ccdm_pack_conv_weight(const float* oihw, int Cout, int Cin, int ksize, int prec, void* out) {
     if (prec != CCDM_PREC_F32 && prec != CCDM_PREC_F16X3) { ccdm::fail("pack: precision %d not built", prec); return 0; }
     int ntiles, NI;
     ccdm::conv_ntiles(Cout, &ntiles, &NI);
-    const int cin_pad = ccdm::conv_cin_pad(Cin), taps = ksize * ksize;
+    const int cin_pad = ccdm::cin_pad_for(Cin, prec), taps = ksize * ksize;
     const size_t frag = ccdm::packed_frag_bytes(Cout, Cin, ksize, prec);
     const size_t total = frag + (prec == CCDM_PREC_F16X3 ? (size_t)ntiles * 32 * sizeof(float) : 0);
     if (!out) return total;

@@ -71,7 +71,7 @@ def test_pack_conv_weight_layout():
         co, ci = nt * 32 + (l & 31), 2 * kp + (l >> 5)
         exp = w[co, ci, tap // 3, tap % 3] if (co < 40 and ci < 6) else 0.0
         assert buf[tap, kp, nt, l] == exp
-    assert hip.load().ccdm_conv_slices(128, 128, 1, 3) == 16
+    assert hip.load().ccdm_conv_slices(128, 128, 1, 3) == 12
     assert hip.load().ccdm_conv_slices(16, 16, 1, 3) == 2
     assert hip.load().ccdm_conv_slices(8, 8, 1, 3) == 1
 

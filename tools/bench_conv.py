@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the conv kernel on the LIDC layer shapes (N=64), through the C ABI.
+Prints per-shape time, algorithmic GB/s and TFLOP/s, and the weighted per-denoise-step total."""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from ccdm_stochastic_segmentation_amd import hip
+
+DEV = torch.device("cuda:0")
+N = int(os.environ.get("N", 64))
+# (count per step, c0, c1, cout, H, W, k, stride, up, gn)
+SHAPES = [
+    (8, 32, 0, 32, 128, 128, 3, 1, 0, 1), (3, 32, 32, 32, 128, 128, 3, 1, 0, 1), (3, 32, 32, 32, 128, 128, 1, 1, 0, 0),
+    (1, 32, 0, 32, 128, 128, 3, 2, 0, 0), (1, 4, 0, 32, 128, 128, 3, 1, 0, 0), (1, 32, 0, 2, 128, 128, 3, 1, 0, 1),
+    (7, 32, 0, 32, 64, 64, 3, 1, 0, 1), (2, 32, 32, 32, 64, 64, 3, 1, 0, 1), (1, 64, 0, 64, 32, 32, 3, 1, 1, 0), (1, 64, 32, 32, 64, 64, 3, 1, 0, 1),
+    (6, 64, 0, 64, 32, 32, 3, 1, 0, 1), (1, 96, 64, 64, 32, 32, 3, 1, 0, 1), (1, 64, 64, 64, 32, 32, 3, 1, 0, 1), (1, 32, 0, 64, 32, 32, 3, 1, 0, 1),
+    (6, 96, 0, 96, 16, 16, 3, 1, 0, 1), (1, 128, 96, 96, 16, 16, 3, 1, 0, 1), (5, 96, 0, 288, 16, 16, 1, 1, 0, 1), (5, 96, 0, 96, 16, 16, 1, 1, 0, 0),
+    (10, 128, 0, 128, 8, 8, 3, 1, 0, 1), (2, 128, 128, 128, 8, 8, 3, 1, 0, 1), (6, 128, 0, 384, 8, 8, 1, 1, 0, 1), (6, 128, 0, 128, 8, 8, 1, 1, 0, 0),
+]
+
+
+def run(prec, shape, iters=20):
+    cnt, c0, c1, cout, H, W, k, stride, up, gn = shape
+    lib = hip.load()
+    g = torch.Generator(device="cpu").manual_seed(0)
+    xa = torch.randn((N, H, W, c0), generator=g).to(DEV)
+    xb = torch.randn((N, H, W, c1), generator=g).to(DEV) if c1 else None
+    cin = c0 + c1
+    w = (torch.randn((cout, cin, k, k), generator=g) / np.sqrt(cin * k * k)).numpy()
+    wd = torch.from_numpy(hip.pack_conv_weight(w, k, prec)).to(DEV)
+    bias = torch.zeros(cout, device=DEV)
+    gam, bet = torch.ones(cin, device=DEV), torch.zeros(cin, device=DEV)
+    Hc, Wc = (2 * H, 2 * W) if up else (H, W)
+    Ho, Wo = (Hc + 2 * (k // 2) - k) // stride + 1, (Wc + 2 * (k // 2) - k) // stride + 1
+    out = torch.empty((N, Ho, Wo, cout), device=DEV)
+    S = lib.ccdm_conv_slices(Ho, Wo, stride, k)
+    ost = torch.empty((N, S, cout, 2), dtype=torch.float64, device=DEV)
+    a = hip.ConvArgs()
+    a.in0, a.C0 = xa.data_ptr(), c0
+    if c1:
+        a.in1, a.C1 = xb.data_ptr(), c1
+    if gn:
+        sa = torch.empty((N, 1, c0, 2), dtype=torch.float64, device=DEV)
+        hip.check(lib.ccdm_gn_stats(xa.data_ptr(), N, H * W, c0, 1, sa.data_ptr(), 0))
+        a.stats0, a.slices0 = sa.data_ptr(), 1
+        if c1:
+            sb = torch.empty((N, 1, c1, 2), dtype=torch.float64, device=DEV)
+            hip.check(lib.ccdm_gn_stats(xb.data_ptr(), N, H * W, c1, 1, sb.data_ptr(), 0))
+            a.stats1, a.slices1 = sb.data_ptr(), 1
+        a.gamma, a.beta, a.act = gam.data_ptr(), bet.data_ptr(), hip.ACT_SILU
+    a.eps = 1e-5
+    a.N, a.Hin, a.Win, a.Hout, a.Wout = N, H, W, Ho, Wo
+    a.ksize, a.stride, a.up = k, stride, up
+    a.w, a.bias, a.Cout, a.prec = wd.data_ptr(), bias.data_ptr(), cout, prec
+    a.emb_off = -1
+    a.out, a.out_stats, a.out_slices = out.data_ptr(), ost.data_ptr(), S
+    for _ in range(3):
+        hip.check(lib.ccdm_conv2d(C.byref(a), 0), "conv")
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        lib.ccdm_conv2d(C.byref(a), 0)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = 2.0 * N * Ho * Wo * cout * cin * k * k
+    byts = 4.0 * N * (cin * H * W + cout * Ho * Wo)
+    return ms, flops / ms / 1e9, byts / ms / 1e6
+
+
+if __name__ == "__main__":
+    precs = [hip.PREC_F16X3] if len(sys.argv) < 2 else [int(v) for v in sys.argv[1].split(",")]
+    only = int(sys.argv[2]) if len(sys.argv) > 2 else None
+    for prec in precs:
+        total = 0.0
+        print(f"--- prec={prec} N={N}")
+        for i, sh in enumerate(SHAPES if only is None else SHAPES[:only]):
+            ms, tf, gbs = run(prec, sh)
+            total += sh[0] * ms
+            print(f"{sh[0]:2d}x {sh[1]+sh[2]:3d}->{sh[3]:3d} @{sh[4]:3d}x{sh[5]:3d} k{sh[6]} s{sh[7]} up{sh[8]} gn{sh[9]}: {ms*1e3:8.1f} us  {tf:7.1f} TF/s  {gbs:7.0f} GB/s(io)")
+        print(f"weighted conv total per denoise step: {total:.3f} ms")
