@@ -123,6 +123,7 @@ __global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI)) void k_conv(const Co
     const int step = a.step_ptr ? *a.step_ptr : 0;
     const int emb_row = (a.emb_row_of_sample ? a.emb_row_of_sample[n] : 0) + step;
     const bool has_gn = a.stats0 != nullptr;
+    const int dbg = a.prec >> 8;          // ablation switches for tools/bench_conv.py (0 in production)
 
     if (has_gn) compute_gn_affine(a, n, emb_row, ab);
 
@@ -242,12 +243,13 @@ __global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI)) void k_conv(const Co
                     for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
         }
         __syncthreads();          // previous MFMA phase has finished reading LDS (and ab[] is visible)
-        commit(it);
+        if (!(dbg & 2)) commit(it);
         __syncthreads();
-        issue(it + 1 < n_iter ? it + 1 : it);    // next tile-chunk's HBM reads fly during the MFMA phase (the last one re-reads its own: harmless, branch-free)
+        if (!(dbg & 4)) issue(it + 1 < n_iter ? it + 1 : it);    // next tile-chunk's HBM reads fly during the MFMA phase (the last one re-reads its own: harmless, branch-free)
 
         const int c0 = chunk * CK;
-        if (PREC == CCDM_PREC_F32) {
+        if (dbg & 1) {
+        } else if (PREC == CCDM_PREC_F32) {
             // taps x 16 k-steps of v_mfma_f32_32x32x2_f32; B: [tap][cin_pad/2][ntiles][64] floats
             const float* wc = reinterpret_cast<const float*>(a.w) + ((size_t)(c0 >> 1) * k.ntiles + nt0) * 64 + lane;
             const size_t wtap = (size_t)(k.cin_pad >> 1) * k.ntiles * 64;
@@ -311,27 +313,30 @@ __global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI)) void k_conv(const Co
                 if (cv) {
                     add = a.bias ? a.bias[co] : 0.f;
                     if (PREC != CCDM_PREC_F32) wsc = k.wscale[co];        // exact power of two
+                    if (a.emb_off >= 0) add += a.emb_table[(size_t)emb_row * a.emb_stride + a.emb_off + co];   // (conv + bias) + emb == conv + (bias + emb) up to 1 ulp
                 }
-                float embv = 0.f;
-                const bool has_emb = a.emb_off >= 0 && cv;
-                if (has_emb) embv = a.emb_table[(size_t)emb_row * a.emb_stride + a.emb_off + co];
+                // per-tile partial statistics in fp32 (<= 32 values per lane), folded into the fp64 running sums once per tile
+                float t1 = 0.f, t2 = 0.f;
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
+                    // pixel of accumulator register r: p = msub*32 + (r&3) + 8*(r>>2) + 4*(lane>>5)
+                    const int pb = (wave * MI + mi) * 32 + 4 * (lane_ >> 5);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int p = (wave * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane_ >> 5);
+                        const int p = pb + (r & 3) + 8 * (r >> 2);
                         const int oy = oy0 + p / TW, ox = ox0 + p % TW;
                         if (cv && oy < a.Hout && ox < a.Wout) {
                             const size_t idx = ((size_t)(n * a.Hout + oy) * a.Wout + ox) * a.Cout + co;
                             float v = (PREC == CCDM_PREC_F32 ? acc[mi][ni][r] : acc[mi][ni][r] * wsc) + add;
-                            if (has_emb) v += embv;
                             if (a.resid) v += a.resid[idx];
-                            a.out[idx] = v;
-                            s1[ni] += (double)v;
-                            s2[ni] += (double)v * (double)v;
+                            if (!(dbg & 8)) a.out[idx] = v;
+                            t1 += v;
+                            t2 = fmaf(v, v, t2);
                         }
                     }
                 }
+                s1[ni] += (double)t1;
+                s2[ni] += (double)t2;
             }
         }
     }
@@ -427,7 +432,7 @@ int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
     CCDM_REQUIRE(a.stride == 1 || a.ksize == 3, "conv: stride 2 is built for 3x3 only");
     CCDM_REQUIRE(a.C0 % 4 == 0 && a.C1 % 4 == 0 && C > 0, "conv: C0=%d C1=%d must be multiples of 4", a.C0, a.C1);
     CCDM_REQUIRE((a.C1 == 0) == (a.in1 == nullptr), "conv: in1/C1 mismatch");
-    CCDM_REQUIRE(a.prec == CCDM_PREC_F32 || a.prec == CCDM_PREC_F16X3, "conv: precision %d not built", a.prec);
+    CCDM_REQUIRE((a.prec & 255) == CCDM_PREC_F32 || (a.prec & 255) == CCDM_PREC_F16X3, "conv: precision %d not built", a.prec);
     if (a.stats0) {
         CCDM_REQUIRE(C % 32 == 0, "conv: GroupNorm(32, %d) needs C %% 32 == 0", C);
         CCDM_REQUIRE(C <= CCDM_MAX_CHANNELS, "conv: %d input channels > CCDM_MAX_CHANNELS", C);
@@ -443,7 +448,8 @@ int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
 
     ConvK k;
     k.a = a;
-    k.cin_pad = cin_pad_for(C, a.prec);
+    const int prec = a.prec & 255;
+    k.cin_pad = cin_pad_for(C, prec);
     int NI;
     conv_ntiles(a.Cout, &k.ntiles, &NI);
     const ConvGeo g = conv_geo(a.Hout, a.Wout, a.stride);
@@ -454,18 +460,18 @@ int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
     k.tiles_x = cdiv(a.Wout, g.TW);
     k.tiles_y = cdiv(a.Hout, g.TH);
     k.slices = conv_slices(a.Hout, a.Wout, a.stride);
-    k.wscale = reinterpret_cast<const float*>(static_cast<const char*>(a.w) + packed_frag_bytes(a.Cout, C, a.ksize, a.prec));
+    k.wscale = reinterpret_cast<const float*>(static_cast<const char*>(a.w) + packed_frag_bytes(a.Cout, C, a.ksize, prec));
     if (a.out_stats) CCDM_REQUIRE(a.out_slices == k.slices, "conv: out_slices %d != %d", a.out_slices, k.slices);
     const int HP = ((g.TH - 1) * a.stride + a.ksize) * ((g.TW - 1) * a.stride + a.ksize);
-    size_t lds = (size_t)HP * (a.prec == CCDM_PREC_F32 ? Lds<CCDM_PREC_F32>::PIXB : Lds<CCDM_PREC_F16X3>::PIXB);
+    size_t lds = (size_t)HP * (prec == CCDM_PREC_F32 ? Lds<CCDM_PREC_F32>::PIXB : Lds<CCDM_PREC_F16X3>::PIXB);
     lds = (lds + 15) / 16 * 16;
-    if (a.prec != CCDM_PREC_F32) lds += (size_t)a.ksize * a.ksize * NI * 128 * 16;     // staged B chunk
+    if (prec != CCDM_PREC_F32) lds += (size_t)a.ksize * a.ksize * NI * 128 * 16;     // staged B chunk
     const size_t red = (size_t)g.waves * NI * 32 * 16;
     if (lds < red) lds = red;
     if (a.stats0) lds += (size_t)C * 8;
     CCDM_REQUIRE(lds <= 160 * 1024, "conv: LDS %zu too large", lds);
     dim3 grid(a.N * k.slices, k.ntiles / NI);
-    const int rc = a.prec == CCDM_PREC_F32 ? launch_prec<CCDM_PREC_F32>(k, g, NI, grid, lds, s)
+    const int rc = prec == CCDM_PREC_F32 ? launch_prec<CCDM_PREC_F32>(k, g, NI, grid, lds, s)
                                            : launch_prec<CCDM_PREC_F16X3>(k, g, NI, grid, lds, s);
     if (rc) return rc;
     CCDM_CHECK_LAUNCH("conv");

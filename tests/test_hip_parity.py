@@ -114,8 +114,9 @@ def test_conv(U, case, prec):
     # fused output statistics == statistics of what was stored
     st = ost.cpu().sum(1)
     gd = got.double()
-    np.testing.assert_allclose(st[..., 0].numpy(), gd.sum((2, 3)).numpy(), rtol=1e-10, atol=1e-8)
-    np.testing.assert_allclose(st[..., 1].numpy(), (gd * gd).sum((2, 3)).numpy(), rtol=1e-10, atol=1e-8)
+    # (per-tile partials are fp32, the running sums fp64: ~1e-6 relative to the sum of |x|)
+    np.testing.assert_allclose(st[..., 0].numpy(), gd.sum((2, 3)).numpy(), rtol=0, atol=2e-6 * gd.abs().sum((2, 3)).max().item())
+    np.testing.assert_allclose(st[..., 1].numpy(), (gd * gd).sum((2, 3)).numpy(), rtol=2e-6, atol=0)
 
 
 def test_conv_rejects_bad_args(U):

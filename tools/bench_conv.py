@@ -23,7 +23,7 @@ SHAPES = [
 ]
 
 
-def run(prec, shape, iters=20):
+def run(prec, shape, iters=20, dbg=0):
     cnt, c0, c1, cout, H, W, k, stride, up, gn = shape
     lib = hip.load()
     g = torch.Generator(device="cpu").manual_seed(0)
@@ -32,6 +32,7 @@ def run(prec, shape, iters=20):
     cin = c0 + c1
     w = (torch.randn((cout, cin, k, k), generator=g) / np.sqrt(cin * k * k)).numpy()
     wd = torch.from_numpy(hip.pack_conv_weight(w, k, prec)).to(DEV)
+    prec = prec | (dbg << 8)
     bias = torch.zeros(cout, device=DEV)
     gam, bet = torch.ones(cin, device=DEV), torch.zeros(cin, device=DEV)
     Hc, Wc = (2 * H, 2 * W) if up else (H, W)
@@ -82,5 +83,10 @@ if __name__ == "__main__":
         for i, sh in enumerate(SHAPES if only is None else SHAPES[:only]):
             ms, tf, gbs = run(prec, sh)
             total += sh[0] * ms
-            print(f"{sh[0]:2d}x {sh[1]+sh[2]:3d}->{sh[3]:3d} @{sh[4]:3d}x{sh[5]:3d} k{sh[6]} s{sh[7]} up{sh[8]} gn{sh[9]}: {ms*1e3:8.1f} us  {tf:7.1f} TF/s  {gbs:7.0f} GB/s(io)")
+            abl = ""
+            if os.environ.get("ABLATE"):
+                # 1: no MFMA, 2: no commit (VALU+LDS writes), 4: no prefetch loads, 8: no stores
+                abl = "  | " + " ".join(f"{nm}={run(prec, sh, dbg=d)[0]*1e3:6.1f}" for nm, d in
+                                        [("-mfma", 1), ("-commit", 2), ("-loads", 4), ("-stores", 8), ("-mfma-commit", 3), ("only-ld/st", 3), ("nothing", 15)])
+            print(f"{sh[0]:2d}x {sh[1]+sh[2]:3d}->{sh[3]:3d} @{sh[4]:3d}x{sh[5]:3d} k{sh[6]} s{sh[7]} up{sh[8]} gn{sh[9]}: {ms*1e3:8.1f} us  {tf:7.1f} TF/s  {gbs:7.0f} GB/s(io){abl}")
         print(f"weighted conv total per denoise step: {total:.3f} ms")
