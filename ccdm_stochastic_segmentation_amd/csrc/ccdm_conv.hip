@@ -135,9 +135,16 @@ __global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI)) void k_conv(const Co
         const int hpix = (p / TW) * STRIDE * HWt + (p % TW) * STRIDE;
         base[mi] = PREC == CCDM_PREC_F32 ? hpix * 33 + (lane >> 5) : hpix * PIXB + (lane >> 5) * 16;   // floats | bytes
     }
-    double s1[NI], s2[NI];
+    // output statistics: slow epilogue -> lane = channel (index 0 used); fast epilogue -> lane = (pixel, channel quad)
+    // (fp32 per lane: <= a few hundred values each; widened to fp64 before lanes, waves and slices are combined)
+    float s1[NI][4], s2[NI][4];
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) { s1[ni] = 0.0; s2[ni] = 0.0; }
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s1[ni][j] = 0.f; s2[ni][j] = 0.f; }
+    const bool fast_epi = (a.Cout & 3) == 0;       // uniform: float4 rows through an LDS transpose
+    constexpr int EPS = 36;                        // floats per pixel row of the transpose buffer (16-B aligned rows)
+    float* epi = reinterpret_cast<float*>(halo_b) + wave * (MI * 32 * EPS);
 
     const int ntile_sp = k.tiles_x * k.tiles_y;
     const int nchunk = k.cin_pad / CK;
@@ -305,6 +312,60 @@ __global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI)) void k_conv(const Co
             const int oy0 = (tile / k.tiles_x) * TH, ox0 = (tile % k.tiles_x) * TW;
             int lane_ = lane;
             asm volatile("" : "+v"(lane_));
+            if (fast_epi) {
+                // ---- fast path: accumulators -> wave-private LDS rows [pixel][32 ch] -> float4 per lane
+                //      (8 lanes cover one pixel's 128-byte row: residual loads and stores move 16 B per lane) ----
+                __syncthreads();                                   // every wave is done reading the A/B tiles
+                const int cq = lane_ & 7, prow = lane_ >> 3;
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int co4 = (nt0 + ni) * 32 + 4 * cq;
+                    const bool cv4 = co4 < a.Cout;
+                    f32x4 rs[MI * 4];
+                    if (a.resid) {
+#pragma unroll
+                        for (int j = 0; j < MI * 4; ++j) {
+                            const int p = wave * MI * 32 + j * 8 + prow;
+                            const int oy = min(oy0 + p / TW, a.Hout - 1), ox = min(ox0 + p % TW, a.Wout - 1);
+                            const int cc = min(co4, a.Cout - 4);
+                            rs[j] = *reinterpret_cast<const f32x4*>(a.resid + ((size_t)(n * a.Hout + oy) * a.Wout + ox) * a.Cout + cc);
+                        }
+                    }
+                    {
+                        const int co = (nt0 + ni) * 32 + (lane_ & 31);
+                        float add = 0.f, wsc = 1.0f;
+                        if (co < a.Cout) {
+                            add = a.bias ? a.bias[co] : 0.f;
+                            if (PREC != CCDM_PREC_F32) wsc = k.wscale[co];
+                            if (a.emb_off >= 0) add += a.emb_table[(size_t)emb_row * a.emb_stride + a.emb_off + co];
+                        }
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int pl = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane_ >> 5);
+                                epi[pl * EPS + (lane_ & 31)] = (PREC == CCDM_PREC_F32 ? acc[mi][ni][r] : acc[mi][ni][r] * wsc) + add;
+                            }
+                    }
+                    float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < MI * 4; ++j) {
+                        const int pl = j * 8 + prow;
+                        const int p = wave * MI * 32 + pl;
+                        const int oy = oy0 + p / TW, ox = ox0 + p % TW;
+                        f32x4 v = *reinterpret_cast<const f32x4*>(epi + pl * EPS + 4 * cq);
+                        if (a.resid) v += rs[j];
+                        if (cv4 && oy < a.Hout && ox < a.Wout) {
+                            if (!(dbg & 8))
+                                *reinterpret_cast<f32x4*>(a.out + ((size_t)(n * a.Hout + oy) * a.Wout + ox) * a.Cout + co4) = v;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { t1[e] += v[e]; t2[e] = fmaf(v[e], v[e], t2[e]); }
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { s1[ni][e] += t1[e]; s2[ni][e] += t2[e]; }
+                }
+            } else {
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
                 const int co = (nt0 + ni) * 32 + (lane_ & 31);
@@ -335,22 +396,39 @@ __global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI)) void k_conv(const Co
                         }
                     }
                 }
-                s1[ni] += (double)t1;
-                s2[ni] += (double)t2;
+                s1[ni][0] += t1;
+                s2[ni][0] += t2;
+            }
             }
         }
     }
 
     if (a.out_stats) {
-        // lanes l and l+32 hold the same channel; then the block's waves; fixed order everywhere
+        // fold the lanes that hold the same channel, then the block's waves; fixed order everywhere
         __syncthreads();
         double* red = reinterpret_cast<double*>(halo_b);     // [WAVES][NI][32][2]
+        if (fast_epi) {
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            const double o1 = __shfl_xor(s1[ni], 32), o2 = __shfl_xor(s2[ni], 32);
-            if (lane < 32) {
-                red[((wave * NI + ni) * 32 + lane) * 2 + 0] = s1[ni] + o1;
-                red[((wave * NI + ni) * 32 + lane) * 2 + 1] = s2[ni] + o2;
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    double v1 = (double)s1[ni][e], v2 = (double)s2[ni][e];
+#pragma unroll
+                    for (int off = 8; off < 64; off <<= 1) { v1 += __shfl_xor(v1, off); v2 += __shfl_xor(v2, off); }
+                    if (lane < 8) {
+                        red[((wave * NI + ni) * 32 + 4 * lane + e) * 2 + 0] = v1;
+                        red[((wave * NI + ni) * 32 + 4 * lane + e) * 2 + 1] = v2;
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const double m1 = (double)s1[ni][0], m2 = (double)s2[ni][0];
+                const double o1 = __shfl_xor(m1, 32), o2 = __shfl_xor(m2, 32);
+                if (lane < 32) {
+                    red[((wave * NI + ni) * 32 + lane) * 2 + 0] = m1 + o1;
+                    red[((wave * NI + ni) * 32 + lane) * 2 + 1] = m2 + o2;
+                }
             }
         }
         __syncthreads();
@@ -468,6 +546,8 @@ int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
     if (prec != CCDM_PREC_F32) lds += (size_t)a.ksize * a.ksize * NI * 128 * 16;     // staged B chunk
     const size_t red = (size_t)g.waves * NI * 32 * 16;
     if (lds < red) lds = red;
+    const size_t epi = (size_t)g.waves * g.MI * 32 * 36 * 4;        // epilogue transpose buffer (wave-private rows)
+    if (lds < epi) lds = epi;
     if (a.stats0) lds += (size_t)C * 8;
     CCDM_REQUIRE(lds <= 160 * 1024, "conv: LDS %zu too large", lds);
     dim3 grid(a.N * k.slices, k.ntiles / NI);
