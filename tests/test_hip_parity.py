@@ -129,12 +129,13 @@ def test_conv_rejects_bad_args(U):
 
 
 # ------------------------------------------------------------------------------------------ attention
-@pytest.mark.parametrize("C,T,order", [(96, 256, 0), (128, 64, 0), (64, 64, 1), (32, 100, 0), (96, 2048, 0)])
+@pytest.mark.parametrize("C,T,order", [(96, 256, 0), (128, 64, 0), (64, 64, 1), (32, 100, 0), (96, 2048, 0), (32, 32, 0), (64, 96, 1),
+                                        (96, 256, 256), (64, 64, 257)])      # order bit 8: force the VALU kernel
 def test_attention_core(U, C, T, order):
     rng = np.random.default_rng(C + T)
     heads = C // 32
     qkv = rnd(rng, 2, 3 * C, T) * 1.3
-    ref = (O.qkv_attention_new if order else O.qkv_attention_legacy)(qkv, heads)        # [N, C, T]
+    ref = (O.qkv_attention_new if (order & 1) else O.qkv_attention_legacy)(qkv, heads)        # [N, C, T]
     got = U.attention(qkv.permute(0, 2, 1).contiguous().to(U.DEV), heads, order).cpu().permute(0, 2, 1)
     np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=0, atol=1e-5)
 
