@@ -45,6 +45,7 @@ __device__ __forceinline__ float silu_fast(float x) {
 struct ConvK {   // kernel-side copy of ccdm_conv_args (+ derived)
     ccdm_conv_args a;
     int cin_pad, ntiles, slices, tiles_x, tiles_y;
+    int cin_pad_skip;        // padded channels of the fused 1x1 skip segment (0: none)
     const float* wscale;     // F16X3: [ntiles*32] powers of two undoing the per-output-channel weight pre-scale
 };
 
@@ -147,7 +148,8 @@ __global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI)) void k_conv(const Co
     float* epi = reinterpret_cast<float*>(halo_b) + wave * (MI * 32 * EPS);
 
     const int ntile_sp = k.tiles_x * k.tiles_y;
-    const int nchunk = k.cin_pad / CK;
+    const int nchunk_main = k.cin_pad / CK;
+    const int nchunk = nchunk_main + k.cin_pad_skip / CK;      // main segment, then the fused 1x1 skip segment
     const int my_tiles = (ntile_sp - slice + k.slices - 1) / k.slices;
     const int n_iter = my_tiles * nchunk;
 
@@ -157,7 +159,13 @@ __global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI)) void k_conv(const Co
 
     // ---- issue: global -> registers for iteration `it` (tile, chunk) ----
     auto issue = [&](int it) {
-        const int tile = slice + (it / nchunk) * k.slices, c0 = (it % nchunk) * CK;
+        const int tile = slice + (it / nchunk) * k.slices;
+        const int ch = it % nchunk;
+        const bool sk = ch >= nchunk_main;                       // uniform: this chunk belongs to the skip segment
+        const int c0 = (sk ? ch - nchunk_main : ch) * CK;
+        const float* src0 = sk ? a.skip0 : a.in0;
+        const float* src1 = sk ? a.skip1 : a.in1;
+        const int sC0 = sk ? a.SC0 : a.C0, sC1 = sk ? a.SC1 : a.C1, sC = sC0 + sC1;
         const int oy0 = (tile / k.tiles_x) * TH, ox0 = (tile % k.tiles_x) * TW;
         valid = 0;
         int t_ = tid;
@@ -169,32 +177,36 @@ __global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI)) void k_conv(const Co
             const int hy = hp / HWt, hx = hp % HWt;                         // compile-time divisors
             const int iy = oy0 * STRIDE - PAD + hy, ix = ox0 * STRIDE - PAD + hx;
             const int c = c0 + 4 * q;
-            const bool ok = item < HP * QPP && iy >= 0 && iy < Hc && ix >= 0 && ix < Wc && c < C;
+            const bool ok = item < HP * QPP && iy >= 0 && iy < Hc && ix >= 0 && ix < Wc && c < sC;
             // branch-free: the load is always issued (address clamped into the tensor), padding is zeroed at commit.
             // A conditional load would put a control-flow join between the prefetch and the MFMA phase, and the
             // waitcnt pass then drains the whole prefetch (vmcnt(0)) at the join.
-            const int iyc = min(max(iy, 0), Hc - 1), ixc = min(max(ix, 0), Wc - 1), cq = min(c, C - 4);
+            const int iyc = min(max(iy, 0), Hc - 1), ixc = min(max(ix, 0), Wc - 1), cq = min(c, sC - 4);
             const int sy = a.up ? (iyc >> 1) : iyc, sx = a.up ? (ixc >> 1) : ixc;
-            const bool first = cq < a.C0;
-            const float* src = first ? a.in0 : a.in1;
-            const int cc = first ? cq : cq - a.C0, Cs = first ? a.C0 : a.C1;
+            const bool first = cq < sC0;
+            const float* src = first ? src0 : src1;
+            const int cc = first ? cq : cq - sC0, Cs = first ? sC0 : sC1;
             reg[i] = *reinterpret_cast<const f32x4*>(src + ((size_t)(n * a.Hin + sy) * a.Win + sx) * Cs + cc);
             valid |= (ok ? 1u : 0u) << i;
         }
         if (PREC != CCDM_PREC_F32) {
-            const f32x4* wq = reinterpret_cast<const f32x4*>(a.w) + ((size_t)(c0 >> 4) * k.ntiles + nt0) * 128;
-            const size_t wtap = (size_t)(k.cin_pad >> 4) * k.ntiles * 128;
+            // skip chunks carry one tap (1x1): only the first NI*128 items are meaningful, the rest re-read them
+            const f32x4* wq = reinterpret_cast<const f32x4*>(sk ? a.skip_w : a.w) + ((size_t)(c0 >> 4) * k.ntiles + nt0) * 128;
+            const size_t wtap = (size_t)((sk ? k.cin_pad_skip : k.cin_pad) >> 4) * k.ntiles * 128;
+            const int nb4 = sk ? NI * 128 : NB4;
 #pragma unroll
             for (int i = 0; i < NITEM_B; ++i) {
                 int j = t_ + i * NT;
-                j = j < NB4 ? j : NB4 - 1;            // unconditional load (keeps regB[] in registers)
+                j = j < nb4 ? j : nb4 - 1;            // unconditional load (keeps regB[] in registers)
                 regB[i] = wq[(size_t)(j / (NI * 128)) * wtap + (j % (NI * 128))];
             }
         }
     };
     // ---- commit: registers -> affine -> SiLU -> LDS (zero where padded) ----
     auto commit = [&](int it) {
-        const int c0 = (it % nchunk) * CK;
+        const int ch = it % nchunk;
+        const bool sk = ch >= nchunk_main;
+        const int c0 = (sk ? ch - nchunk_main : ch) * CK;
         int t_ = tid;
         asm volatile("" : "+v"(t_));
 #pragma unroll
@@ -205,13 +217,13 @@ __global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI)) void k_conv(const Co
                 float4 v = make_float4(reg[i][0], reg[i][1], reg[i][2], reg[i][3]);
                 if (!((valid >> i) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 else {
-                    if (has_gn) {
+                    if (has_gn && !sk) {
                         const int c = c0 + 4 * q;
                         const float2 t0 = ab[c], t1 = ab[c + 1], t2 = ab[c + 2], t3 = ab[c + 3];
                         v.x = fmaf(v.x, t0.x, t0.y); v.y = fmaf(v.y, t1.x, t1.y);
                         v.z = fmaf(v.z, t2.x, t2.y); v.w = fmaf(v.w, t3.x, t3.y);
                     }
-                    if (a.act == CCDM_ACT_SILU) { v.x = silu_fast(v.x); v.y = silu_fast(v.y); v.z = silu_fast(v.z); v.w = silu_fast(v.w); }
+                    if (a.act == CCDM_ACT_SILU && !sk) { v.x = silu_fast(v.x); v.y = silu_fast(v.y); v.z = silu_fast(v.z); v.w = silu_fast(v.w); }
                 }
                 if (PREC == CCDM_PREC_F32) {
                     float* d = halo + hp * 33 + 4 * q;
@@ -254,16 +266,18 @@ __global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI)) void k_conv(const Co
         __syncthreads();
         if (!(dbg & 4)) issue(it + 1 < n_iter ? it + 1 : it);    // next tile-chunk's HBM reads fly during the MFMA phase (the last one re-reads its own: harmless, branch-free)
 
-        const int c0 = chunk * CK;
+        const bool skc = chunk >= nchunk_main;                   // uniform
+        const int c0 = (skc ? chunk - nchunk_main : chunk) * CK;
         if (dbg & 1) {
         } else if (PREC == CCDM_PREC_F32) {
             // taps x 16 k-steps of v_mfma_f32_32x32x2_f32; B: [tap][cin_pad/2][ntiles][64] floats
-            const float* wc = reinterpret_cast<const float*>(a.w) + ((size_t)(c0 >> 1) * k.ntiles + nt0) * 64 + lane;
+            const float* wc = reinterpret_cast<const float*>(skc ? a.skip_w : a.w) + ((size_t)(c0 >> 1) * k.ntiles + nt0) * 64 + lane;
             const size_t wtap = (size_t)(k.cin_pad >> 1) * k.ntiles * 64;
 #pragma unroll
             for (int tap = 0; tap < KS * KS; ++tap) {
+                if (skc && tap != (KS * KS) / 2) continue;       // skip segment: centre tap only, its weights are tap 0
                 const int toff = ((tap / KS) * HWt + (tap % KS)) * 33;
-                const float* wt = wc + tap * wtap;
+                const float* wt = wc + (skc ? 0 : tap * wtap);
 #pragma unroll 4
                 for (int kk = 0; kk < CK / 2; ++kk) {
                     float av[MI];
@@ -284,6 +298,8 @@ __global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI)) void k_conv(const Co
             const f16x8* bq = reinterpret_cast<const f16x8*>(ldsB) + lane;
 #pragma unroll
             for (int tap = 0; tap < KS * KS; ++tap) {
+                if (skc && tap != (KS * KS) / 2) continue;       // skip segment: centre tap only, staged as B slot 0
+                const int bt = skc ? 0 : tap;
                 const int toff = ((tap / KS) * HWt + (tap % KS)) * PIXB;
                 f16x8 ah[MI], al[MI];
 #pragma unroll
@@ -294,8 +310,8 @@ __global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI)) void k_conv(const Co
                 }
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
-                    const f16x8 bh = bq[(tap * NI + ni) * 128];
-                    const f16x8 bl = bq[(tap * NI + ni) * 128 + 64];
+                    const f16x8 bh = bq[(bt * NI + ni) * 128];
+                    const f16x8 bl = bq[(bt * NI + ni) * 128 + 64];
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh, acc[mi][ni], 0, 0, 0);
 #pragma unroll
@@ -519,6 +535,12 @@ int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
         CCDM_REQUIRE(a.slices0 >= 1 && (a.C1 == 0 || a.slices1 >= 1), "conv: bad stats slices");
     }
     CCDM_REQUIRE(!a.film || (a.stats0 && a.emb_table), "conv: FiLM needs GroupNorm and an emb table");
+    if (a.skip0) {
+        CCDM_REQUIRE(a.stride == 1 && !a.up && a.skip_w, "conv: fused skip needs stride 1, no upsample, packed skip_w");
+        CCDM_REQUIRE(a.SC0 % 4 == 0 && a.SC1 % 4 == 0 && a.SC0 > 0, "conv: skip channels %d/%d must be multiples of 4", a.SC0, a.SC1);
+        CCDM_REQUIRE((a.SC1 == 0) == (a.skip1 == nullptr), "conv: skip1/SC1 mismatch");
+        CCDM_REQUIRE(a.Hin == a.Hout && a.Win == a.Wout, "conv: fused skip needs equal input and output size");
+    }
     const int Hc = a.up ? 2 * a.Hin : a.Hin, Wc = a.up ? 2 * a.Win : a.Win;
     const int pad = a.ksize / 2;
     CCDM_REQUIRE(a.Hout == (Hc + 2 * pad - a.ksize) / a.stride + 1 && a.Wout == (Wc + 2 * pad - a.ksize) / a.stride + 1,
@@ -528,6 +550,7 @@ int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
     k.a = a;
     const int prec = a.prec & 255;
     k.cin_pad = cin_pad_for(C, prec);
+    k.cin_pad_skip = a.skip0 ? cin_pad_for(a.SC0 + a.SC1, prec) : 0;
     int NI;
     conv_ntiles(a.Cout, &k.ntiles, &NI);
     const ConvGeo g = conv_geo(a.Hout, a.Wout, a.stride);
@@ -579,7 +602,13 @@ extern "C" int ccdm_conv2d(const ccdm_conv_args* a, void* stream) {
 //                   into fp16 hi + lo (v_mfma_f32_32x32x16_f16), followed by [ntiles*32] floats 2^-e(cout).
 //                   The per-output-channel power of two puts max|W| of the channel in [2^9, 2^10) so hi and lo
 //                   both sit in fp16's normal range; it is exact and undone exactly in the epilogue.
+extern "C" size_t ccdm_pack_conv_weight_ex(const float* oihw, int Cout, int Cin, int ksize, int prec, const float* cout_absmax, void* out);
+
 extern "C" size_t ccdm_pack_conv_weight(const float* oihw, int Cout, int Cin, int ksize, int prec, void* out) {
+    return ccdm_pack_conv_weight_ex(oihw, Cout, Cin, ksize, prec, nullptr, out);
+}
+
+extern "C" size_t ccdm_pack_conv_weight_ex(const float* oihw, int Cout, int Cin, int ksize, int prec, const float* cout_absmax, void* out) {
     if (prec != CCDM_PREC_F32 && prec != CCDM_PREC_F16X3) { ccdm::fail("pack: precision %d not built", prec); return 0; }
     int ntiles, NI;
     ccdm::conv_ntiles(Cout, &ntiles, &NI);
@@ -605,8 +634,10 @@ extern "C" size_t ccdm_pack_conv_weight(const float* oihw, int Cout, int Cin, in
     std::vector<float> mul(ntiles * 32, 1.0f);
     for (int co = 0; co < ntiles * 32; ++co) {
         float mx = 0.f;
-        if (co < Cout)
-            for (size_t i = 0; i < (size_t)Cin * taps; ++i) mx = fmaxf(mx, fabsf(oihw[(size_t)co * Cin * taps + i]));
+        if (co < Cout) {
+            if (cout_absmax) mx = cout_absmax[co];
+            else for (size_t i = 0; i < (size_t)Cin * taps; ++i) mx = fmaxf(mx, fabsf(oihw[(size_t)co * Cin * taps + i]));
+        }
         int e = 0;
         if (mx > 0.f && std::isfinite(mx)) { int ex; frexpf(mx, &ex); e = 10 - ex; }     // mx*2^e in [2^9, 2^10)
         if (e > 60) e = 60;

@@ -99,7 +99,8 @@ class SamplerEngine:
     # ------------------------------------------------------------------ op emission
     def _conv(self, src: Sequence[DevTensor], wkey: str, cout: int, ksize: int, *, gn: Optional[str] = None,
               act: int = hip.ACT_NONE, stride: int = 1, up: bool = False, emb_off: int = -1,
-              film_off: int = -1, resid: Optional[DevTensor] = None, stats: bool = True) -> DevTensor:
+              film_off: int = -1, resid: Optional[DevTensor] = None, stats: bool = True,
+              skip_src: Optional[Sequence[DevTensor]] = None, skip_key: Optional[str] = None) -> DevTensor:
         sd = self._sd
         a, b = src[0], (src[1] if len(src) > 1 else None)
         cin = a.C + (b.C if b else 0)
@@ -109,8 +110,16 @@ class SamplerEngine:
             wp = np.zeros((cout, cin) + tuple(w.shape[2:]), np.float32)
             wp[:, : w.shape[1]] = w
             w = wp
-        wdev = self._upload(hip.pack_conv_weight(w, ksize, self.prec))
-        bias = self._upload(sd[wkey + ".bias"].numpy())
+        bias_np = sd[wkey + ".bias"].numpy()
+        absmax = None
+        if skip_src is not None:
+            # the 1x1 skip connection rides in the same GEMM: shared F16X3 exponents, biases pre-added
+            ws = sd[skip_key + ".weight"].numpy().reshape(cout, -1)
+            absmax = np.maximum(np.abs(w.reshape(cout, -1)).max(1), np.abs(ws).max(1)).astype(np.float32)
+            skip_w = self._upload(hip.pack_conv_weight(ws.reshape(cout, -1, 1, 1), 1, self.prec, absmax))
+            bias_np = bias_np + sd[skip_key + ".bias"].numpy()
+        wdev = self._upload(hip.pack_conv_weight(w, ksize, self.prec, absmax))
+        bias = self._upload(bias_np)
         hin, win = a.h, a.w
         hc, wc = (2 * hin, 2 * win) if up else (hin, win)
         pad = ksize // 2
@@ -139,6 +148,12 @@ class SamplerEngine:
             assert (resid.C, resid.h, resid.w) == (cout, hout, wout), wkey
         args.out = out.ptr
         args.out_stats, args.out_slices = out.stats_ptr, out.slices
+        if skip_src is not None:
+            sa, sb = skip_src[0], (skip_src[1] if len(skip_src) > 1 else None)
+            assert (sa.h, sa.w) == (hout, wout), wkey
+            args.skip0, args.SC0 = sa.ptr, sa.C
+            args.skip1, args.SC1 = (sb.ptr, sb.C) if sb else (0, 0)
+            args.skip_w = skip_w.data_ptr()
         hip.check(self.lib.ccdm_engine_add_conv(self._handle, C.byref(args)), "engine_add_conv " + wkey)
         self.op_names.append(wkey)
         return out
@@ -150,13 +165,13 @@ class SamplerEngine:
         else:
             h = self._conv(src, p + ".in_layers.2", l.cout, 3, gn=p + ".in_layers.0", act=hip.ACT_SILU, emb_off=off)
         if l.has_skip_conv:
-            skip = self._conv(src, p + ".skip_connection", l.cout, 1, stats=False)
-        else:
-            if len(src) != 1:
-                raise NotImplementedError(f"{p}: identity skip on a concatenated input")
-            skip = src[0]
+            # skip_connection (1x1 conv of the block input) is fused into the second conv as extra K-segments
+            return self._conv([h], p + ".out_layers.3", l.cout, 3, gn=p + ".out_layers.0", act=hip.ACT_SILU,
+                              film_off=off if l.film else -1, skip_src=src, skip_key=p + ".skip_connection")
+        if len(src) != 1:
+            raise NotImplementedError(f"{p}: identity skip on a concatenated input")
         return self._conv([h], p + ".out_layers.3", l.cout, 3, gn=p + ".out_layers.0", act=hip.ACT_SILU,
-                          film_off=off if l.film else -1, resid=skip)
+                          film_off=off if l.film else -1, resid=src[0])
 
     def _attn(self, p: str, l, x: DevTensor) -> DevTensor:
         qkv = self._conv([x], p + ".qkv", 3 * l.ch, 1, gn=p + ".norm", act=hip.ACT_NONE, stats=False)

@@ -40,6 +40,8 @@ class ConvArgs(C.Structure):
         ("resid", C.c_void_p),
         ("out", C.c_void_p),
         ("out_stats", C.c_void_p), ("out_slices", C.c_int32),
+        ("skip0", C.c_void_p), ("skip1", C.c_void_p), ("SC0", C.c_int32), ("SC1", C.c_int32),
+        ("skip_w", C.c_void_p),
     ]
 
 
@@ -67,6 +69,7 @@ SIGNATURES = {
     "ccdm_conv_slices": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "ccdm_conv2d": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "ccdm_pack_conv_weight": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ccdm_pack_conv_weight_ex": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ccdm_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ccdm_time_table": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -139,16 +142,22 @@ def check(rc: int, what: str = "") -> int:
     return rc
 
 
-def pack_conv_weight(w, ksize: int, prec: int = PREC_F32):
-    """OIHW / OIK numpy fp32 -> packed numpy uint8 buffer (host-side, no GPU needed)."""
+def pack_conv_weight(w, ksize: int, prec: int = PREC_F32, cout_absmax=None):
+    """OIHW / OIK numpy fp32 -> packed numpy uint8 buffer (host-side, no GPU needed).
+    cout_absmax: optional [Cout] fp32 max|W| per output channel shared by several weight sets of one GEMM."""
     import numpy as np
     lib = load()
     w = np.ascontiguousarray(w, dtype=np.float32)
     cout, cin = int(w.shape[0]), int(w.shape[1])
     assert w.size == cout * cin * ksize * ksize, (w.shape, ksize)
-    nbytes = lib.ccdm_pack_conv_weight(None, cout, cin, ksize, prec, None)
+    am = None
+    if cout_absmax is not None:
+        am = np.ascontiguousarray(cout_absmax, dtype=np.float32)
+        assert am.shape == (cout,)
+    amp = am.ctypes.data if am is not None else None
+    nbytes = lib.ccdm_pack_conv_weight_ex(None, cout, cin, ksize, prec, amp, None)
     if nbytes == 0:
         raise CcdmHipError("pack_conv_weight: " + last_error())
     out = np.empty(nbytes, dtype=np.uint8)
-    lib.ccdm_pack_conv_weight(w.ctypes.data, cout, cin, ksize, prec, out.ctypes.data)
+    lib.ccdm_pack_conv_weight_ex(w.ctypes.data, cout, cin, ksize, prec, amp, out.ctypes.data)
     return out

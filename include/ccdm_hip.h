@@ -73,6 +73,12 @@ typedef struct ccdm_conv_args {
     const float* resid;                             /* dev [N,Hout,Wout,Cout] added last, or NULL */
     float* out;                                     /* dev [N,Hout,Wout,Cout] */
     double* out_stats; int32_t out_slices;          /* dev [N,out_slices,Cout,2] or NULL; out_slices = ccdm_conv_slices() */
+    /* fused 1x1 skip connection (ResBlock.skip_connection, unet.py:221-228,262): out += W_s * [skip0 | skip1] as extra
+     * K-segments of the same GEMM (raw input, centre tap).  skip_w is packed with ksize 1 and the SAME per-channel
+     * exponents as w (ccdm_pack_conv_weight_ex with a shared absmax); its bias is pre-added into `bias` by the host.
+     * Requires stride 1, up 0, skip tensors [N,Hout,Wout,SC*].  skip0 == NULL: none. */
+    const float* skip0; const float* skip1; int32_t SC0; int32_t SC1;
+    const void* skip_w;
 } ccdm_conv_args;
 
 /* number of statistics slices the conv kernel produces for an Hout x Wout output (depends only on the
@@ -83,6 +89,9 @@ int ccdm_conv2d(const ccdm_conv_args* a, void* stream);
 /* host-side weight packing.  `oihw` = reference layout [Cout,Cin,k,k] (conv2d) / [Cout,Cin,1] (conv1d).
  * Returns the packed size in bytes (call with out=NULL to query). */
 size_t ccdm_pack_conv_weight(const float* oihw, int Cout, int Cin, int ksize, int prec, void* out);
+/* same, with the per-output-channel max|W| given by the caller (dev-independent host array [Cout], or NULL): two weight
+ * sets that accumulate into one GEMM (conv + fused skip) must share their F16X3 power-of-two pre-scale. */
+size_t ccdm_pack_conv_weight_ex(const float* oihw, int Cout, int Cin, int ksize, int prec, const float* cout_absmax, void* out);
 
 /* ---------------------------------------------------------------------------------------------------
  * Self-attention core over tokens, softmax(q k^T * ch^-1/2) v per head, streaming (score matrix never in HBM).

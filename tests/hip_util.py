@@ -30,7 +30,7 @@ def gn_stats(x_nhwc: torch.Tensor, slices: int = 1) -> torch.Tensor:
 
 
 def conv2d(srcs, weight, bias, ksize, *, stats=None, gamma=None, beta=None, act=hip.ACT_NONE, stride=1, up=False,
-           emb=None, emb_rows=None, film=None, resid=None, want_stats=True, prec=hip.PREC_F32):
+           emb=None, emb_rows=None, film=None, resid=None, want_stats=True, prec=hip.PREC_F32, skip=None):
     """srcs: list of 1-2 NHWC cuda tensors; weight OIHW numpy/torch cpu; stats: list of stats tensors or None.
     emb: [rows, E] cpu tensor added per output channel (row per sample via emb_rows) ; film: (table cpu [rows, 2C]).
     Returns (out NHWC cuda, out_stats or None)."""
@@ -41,8 +41,16 @@ def conv2d(srcs, weight, bias, ksize, *, stats=None, gamma=None, beta=None, act=
     C1 = b.shape[3] if b is not None else 0
     w = np.ascontiguousarray(weight, dtype=np.float32)
     cout = w.shape[0]
-    wdev = torch.from_numpy(hip.pack_conv_weight(w, ksize, prec)).to(DEV)
-    bdev = torch.as_tensor(np.asarray(bias, dtype=np.float32)).to(DEV)
+    absmax = None
+    bias = np.asarray(bias, dtype=np.float32)
+    if skip is not None:            # (list of NHWC tensors, weight [Cout,Cs,1,1], bias): fused 1x1 skip connection
+        ssrc, sw, sb = skip
+        sw = np.ascontiguousarray(sw, dtype=np.float32).reshape(cout, -1)
+        absmax = np.maximum(np.abs(w.reshape(cout, -1)).max(1), np.abs(sw).max(1)).astype(np.float32)
+        swdev = torch.from_numpy(hip.pack_conv_weight(sw.reshape(cout, -1, 1, 1), 1, prec, absmax)).to(DEV)
+        bias = bias + np.asarray(sb, dtype=np.float32)
+    wdev = torch.from_numpy(hip.pack_conv_weight(w, ksize, prec, absmax)).to(DEV)
+    bdev = torch.as_tensor(bias).to(DEV)
     Hc, Wc = (2 * Hin, 2 * Win) if up else (Hin, Win)
     pad = ksize // 2
     Hout, Wout = (Hc + 2 * pad - ksize) // stride + 1, (Wc + 2 * pad - ksize) // stride + 1
@@ -78,6 +86,12 @@ def conv2d(srcs, weight, bias, ksize, *, stats=None, gamma=None, beta=None, act=
             args.film, args.film_off = 1, 0
     if resid is not None:
         args.resid = resid.data_ptr()
+    if skip is not None:
+        keep.append(swdev)
+        args.skip0, args.SC0 = ssrc[0].data_ptr(), ssrc[0].shape[3]
+        if len(ssrc) > 1:
+            args.skip1, args.SC1 = ssrc[1].data_ptr(), ssrc[1].shape[3]
+        args.skip_w = swdev.data_ptr()
     args.out = out.data_ptr()
     ost = None
     if want_stats:

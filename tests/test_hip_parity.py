@@ -119,6 +119,32 @@ def test_conv(U, case, prec):
     np.testing.assert_allclose(st[..., 1].numpy(), (gd * gd).sum((2, 3)).numpy(), rtol=2e-6, atol=0)
 
 
+@pytest.mark.parametrize("prec", PRECS, ids=PREC_IDS)
+@pytest.mark.parametrize("c0,c1,cout,H,W", [(64, 32, 32, 32, 32), (128, 96, 96, 16, 16), (256, 0, 128, 8, 8), (64, 0, 32, 40, 24)])
+def test_conv_with_fused_skip(U, prec, c0, c1, cout, H, W):
+    """ResBlock tail: conv3x3(SiLU(GN(h))) + b  +  conv1x1([xa|xb]) + bs in ONE launch (skip as extra K segments)."""
+    rng = np.random.default_rng(c0 + cout + H)
+    N = 2
+    h = rnd(rng, N, cout, H, W) * 1.2
+    xa = rnd(rng, N, c0, H, W) * 1.5 + 0.2
+    xb = rnd(rng, N, c1, H, W) * 0.8 if c1 else None
+    x = torch.cat([xa, xb], 1) if c1 else xa
+    w = rnd(rng, cout, cout, 3, 3) / np.sqrt(cout * 9)
+    b = rnd(rng, cout, scale=0.1)
+    ws = rnd(rng, cout, c0 + c1, 1, 1) / np.sqrt(c0 + c1) * 3.0      # different magnitude than w: shared exponents matter
+    bs = rnd(rng, cout, scale=0.1)
+    gamma, beta = 1 + rnd(rng, cout, scale=0.1), rnd(rng, cout, scale=0.1)
+    ref = F.conv2d(F.silu(F.group_norm(h, 32, gamma, beta, 1e-5)), w, b, padding=1) + F.conv2d(x, ws, bs)
+    hs = U.nhwc(h)
+    out, ost = U.conv2d([hs], w.numpy(), b.numpy(), 3, stats=[U.gn_stats(hs, 1)], gamma=gamma.numpy(), beta=beta.numpy(),
+                        act=hip.ACT_SILU, prec=prec,
+                        skip=([U.nhwc(xa)] + ([U.nhwc(xb)] if c1 else []), ws.numpy(), bs.numpy()))
+    got = U.bchw(out)
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=0, atol=3e-5)
+    gd = got.double()
+    np.testing.assert_allclose(ost.cpu().sum(1)[..., 0].numpy(), gd.sum((2, 3)).numpy(), rtol=0, atol=2e-6 * gd.abs().sum((2, 3)).max().item())
+
+
 def test_conv_rejects_bad_args(U):
     x = torch.zeros((1, 8, 8, 6), device=U.DEV)
     with pytest.raises(hip.CcdmHipError, match="multiples of 4"):
@@ -152,12 +178,11 @@ def _run_block(U, kind, kw, sd, x, emb, prec):
         h, hst = U.conv2d([xs], sd[p + "in_layers.2.weight"].numpy(), sd[p + "in_layers.2.bias"].numpy(), 3, stats=[st],
                           gamma=sd[p + "in_layers.0.weight"].numpy(), beta=sd[p + "in_layers.0.bias"].numpy(), act=hip.ACT_SILU,
                           emb=None if film else e.numpy(), emb_rows=np.arange(N), prec=prec)
-        skip = xs
-        if (p + "skip_connection.weight") in sd:
-            skip, _ = U.conv2d([xs], sd[p + "skip_connection.weight"].numpy(), sd[p + "skip_connection.bias"].numpy(), 1, want_stats=False, prec=prec)
+        has_skip = (p + "skip_connection.weight") in sd
         y, _ = U.conv2d([h], sd[p + "out_layers.3.weight"].numpy(), sd[p + "out_layers.3.bias"].numpy(), 3, stats=[hst],
                         gamma=sd[p + "out_layers.0.weight"].numpy(), beta=sd[p + "out_layers.0.bias"].numpy(), act=hip.ACT_SILU,
-                        film=e.numpy() if film else None, emb_rows=np.arange(N), resid=skip, prec=prec)
+                        film=e.numpy() if film else None, emb_rows=np.arange(N), resid=None if has_skip else xs, prec=prec,
+                        skip=([xs], sd[p + "skip_connection.weight"].numpy(), sd[p + "skip_connection.bias"].numpy()) if has_skip else None)
         return U.bchw(y)
     if kind == "attn":
         C_ = kw["ch"]

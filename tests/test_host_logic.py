@@ -47,8 +47,9 @@ def test_struct_layout_matches_header():
     #include <stddef.h>
     #include "ccdm_hip.h"
     int main(){
-      printf("%zu %zu %zu %zu %zu %zu\n", sizeof(ccdm_conv_args), offsetof(ccdm_conv_args, gamma), offsetof(ccdm_conv_args, w),
-             offsetof(ccdm_conv_args, emb_row_of_sample), offsetof(ccdm_conv_args, out), offsetof(ccdm_conv_args, out_slices));
+      printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(ccdm_conv_args), offsetof(ccdm_conv_args, gamma), offsetof(ccdm_conv_args, w),
+             offsetof(ccdm_conv_args, emb_row_of_sample), offsetof(ccdm_conv_args, out), offsetof(ccdm_conv_args, out_slices),
+             offsetof(ccdm_conv_args, SC1), offsetof(ccdm_conv_args, skip_w));
       printf("%zu %zu %zu %zu %zu\n", sizeof(ccdm_post_args), offsetof(ccdm_post_args, step_table), offsetof(ccdm_post_args, philox_seed),
              offsetof(ccdm_post_args, xin_stride), offsetof(ccdm_post_args, posterior_out));
       return 0; }'''
@@ -59,6 +60,7 @@ def test_struct_layout_matches_header():
         out = subprocess.check_output([os.path.join(d, "t")]).decode().split()
     A, B = hip.ConvArgs, hip.PostArgs
     mine = [ctypes.sizeof(A), A.gamma.offset, A.w.offset, A.emb_row_of_sample.offset, A.out.offset, A.out_slices.offset,
+            A.SC1.offset, A.skip_w.offset,
             ctypes.sizeof(B), B.step_table.offset, B.philox_seed.offset, B.xin_stride.offset, B.posterior_out.offset]
     assert [int(v) for v in out] == mine
 
