@@ -99,6 +99,7 @@ __global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI)) void k_conv(const Co
     constexpr int QPP = CK / 4;                                   // float4 items per halo pixel
     constexpr int NITEM = (HP * QPP + NT - 1) / NT;               // staging items per thread
     static_assert(NITEM <= 32, "validity mask is 32 bits");
+    static_assert(NT % QPP == 0, "channel quad must be item-invariant");
     constexpr int A_BYTES = (HP * PIXB + 15) / 16 * 16;
     // F16X3: the chunk's B fragments, [tap][ni][hi|lo][64 lanes] x 16 B, staged through registers like the halo
     constexpr int NB4 = PREC == CCDM_PREC_F32 ? 0 : KS * KS * NI * 128;
@@ -127,6 +128,11 @@ __global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI)) void k_conv(const Co
     const int dbg = a.prec >> 8;          // ablation switches for tools/bench_conv.py (0 in production)
 
     if (has_gn) compute_gn_affine(a, n, emb_row, ab);
+    const int aWout = a.Wout, aCout = a.Cout, aHout = a.Hout, aWin = a.Win;
+    const size_t in_px = (size_t)a.Hin * a.Win;
+    const size_t out_px = (size_t)a.Hout * a.Wout;
+    float* outn = a.out + (size_t)n * out_px * aCout;
+    const float* residn = a.resid + (size_t)n * out_px * aCout;   // guarded by a.resid at the uses
 
     // per-lane LDS base of each of this wave's 32-pixel sub-tiles (A operand: row = lane&31, k-group = lane>>5)
     int base[MI];
@@ -163,31 +169,40 @@ __global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI)) void k_conv(const Co
         const int ch = it % nchunk;
         const bool sk = ch >= nchunk_main;                       // uniform: this chunk belongs to the skip segment
         const int c0 = (sk ? ch - nchunk_main : ch) * CK;
-        const float* src0 = sk ? a.skip0 : a.in0;
-        const float* src1 = sk ? a.skip1 : a.in1;
-        const int sC0 = sk ? a.SC0 : a.C0, sC1 = sk ? a.SC1 : a.C1, sC = sC0 + sC1;
+        const int sC0 = sk ? a.SC0 : a.C0, sC1 = sk ? a.SC1 : a.C1;
+        // a chunk never straddles the concat seam (launcher: C0 % CK == 0 when there is a second source)
+        const bool second = sC1 > 0 && c0 >= sC0;                 // uniform
+        const int Cs = second ? sC1 : sC0, cb = second ? c0 - sC0 : c0;
+        const float* srcsel = sk ? (second ? a.skip1 : a.skip0) : (second ? a.in1 : a.in0);
+        const float* srcb = srcsel + (size_t)n * (sk ? out_px : in_px) * Cs;      // uniform per-sample base
         const int oy0 = (tile / k.tiles_x) * TH, ox0 = (tile % k.tiles_x) * TW;
         valid = 0;
-        int t_ = tid;
+        unsigned t_ = tid;
         asm volatile("" : "+v"(t_));     // recompute the item geometry each call: hoisting it costs more registers than ALU
+        // item = tid + i*NT  ->  halo pixel hp = item / QPP (hy = hp / HWt, hx = hp % HWt), channel quad q = item % QPP.
+        // NT % QPP == 0, so q is the same for every i and hp advances by NT/QPP: (hy, hx) are carried incrementally
+        // (unsigned, no per-item division).
+        constexpr unsigned DHP = NT / QPP, DHY = DHP / HWt, DHX = DHP % HWt;
+        const unsigned q = t_ % QPP, hp0 = t_ / QPP;
+        unsigned hy = hp0 / HWt, hx = hp0 % HWt;
+        const unsigned c = (unsigned)cb + 4u * q;
+        const unsigned cq = min(c, (unsigned)Cs - 4u);
+        const bool cok = c < (unsigned)Cs;
 #pragma unroll
         for (int i = 0; i < NITEM; ++i) {
-            const int item = t_ + i * NT;
-            const int hp = item / QPP, q = item % QPP;
-            const int hy = hp / HWt, hx = hp % HWt;                         // compile-time divisors
-            const int iy = oy0 * STRIDE - PAD + hy, ix = ox0 * STRIDE - PAD + hx;
-            const int c = c0 + 4 * q;
-            const bool ok = item < HP * QPP && iy >= 0 && iy < Hc && ix >= 0 && ix < Wc && c < sC;
+            const int iy = oy0 * STRIDE - PAD + (int)hy, ix = ox0 * STRIDE - PAD + (int)hx;
+            // padding test: unsigned compare folds the < 0 and >= extent checks; no short-circuit branches
+            const bool ok = cok & ((unsigned)iy < (unsigned)Hc) & ((unsigned)ix < (unsigned)Wc) & (hy < (unsigned)HHt);
             // branch-free: the load is always issued (address clamped into the tensor), padding is zeroed at commit.
             // A conditional load would put a control-flow join between the prefetch and the MFMA phase, and the
             // waitcnt pass then drains the whole prefetch (vmcnt(0)) at the join.
-            const int iyc = min(max(iy, 0), Hc - 1), ixc = min(max(ix, 0), Wc - 1), cq = min(c, sC - 4);
+            const int iyc = min(max(iy, 0), Hc - 1), ixc = min(max(ix, 0), Wc - 1);
             const int sy = a.up ? (iyc >> 1) : iyc, sx = a.up ? (ixc >> 1) : ixc;
-            const bool first = cq < sC0;
-            const float* src = first ? src0 : src1;
-            const int cc = first ? cq : cq - sC0, Cs = first ? sC0 : sC1;
-            reg[i] = *reinterpret_cast<const f32x4*>(src + ((size_t)(n * a.Hin + sy) * a.Win + sx) * Cs + cc);
+            const unsigned off = ((unsigned)(sy * aWin + sx) * (unsigned)Cs + cq) << 2;      // bytes within the sample
+            reg[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(srcb) + off);
             valid |= (ok ? 1u : 0u) << i;
+            hy += DHY; hx += DHX;
+            if (hx >= (unsigned)HWt) { hx -= HWt; hy += 1; }
         }
         if (PREC != CCDM_PREC_F32) {
             // skip chunks carry one tap (1x1): only the first NI*128 items are meaningful, the rest re-read them
@@ -196,7 +211,7 @@ __global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI)) void k_conv(const Co
             const int nb4 = sk ? NI * 128 : NB4;
 #pragma unroll
             for (int i = 0; i < NITEM_B; ++i) {
-                int j = t_ + i * NT;
+                int j = (int)t_ + i * NT;
                 j = j < nb4 ? j : nb4 - 1;            // unconditional load (keeps regB[] in registers)
                 regB[i] = wq[(size_t)(j / (NI * 128)) * wtap + (j % (NI * 128))];
             }
@@ -207,13 +222,14 @@ __global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI)) void k_conv(const Co
         const int ch = it % nchunk;
         const bool sk = ch >= nchunk_main;
         const int c0 = (sk ? ch - nchunk_main : ch) * CK;
-        int t_ = tid;
+        unsigned t_ = tid;
         asm volatile("" : "+v"(t_));
+        const unsigned q = t_ % QPP;
 #pragma unroll
         for (int i = 0; i < NITEM; ++i) {
-            const int item = t_ + i * NT;
-            if (item < HP * QPP) {
-                const int hp = item / QPP, q = item % QPP;
+            const unsigned item = t_ + i * NT;
+            if (item < (unsigned)(HP * QPP)) {
+                const unsigned hp = item / QPP;
                 float4 v = make_float4(reg[i][0], reg[i][1], reg[i][2], reg[i][3]);
                 if (!((valid >> i) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 else {
@@ -243,7 +259,7 @@ __global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI)) void k_conv(const Co
         if (PREC != CCDM_PREC_F32) {
 #pragma unroll
             for (int i = 0; i < NITEM_B; ++i) {
-                const int j = t_ + i * NT;
+                const int j = (int)t_ + i * NT;
                 if (j < NB4) ldsB[j] = regB[i];
             }
         }
@@ -342,9 +358,9 @@ __global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI)) void k_conv(const Co
 #pragma unroll
                         for (int j = 0; j < MI * 4; ++j) {
                             const int p = wave * MI * 32 + j * 8 + prow;
-                            const int oy = min(oy0 + p / TW, a.Hout - 1), ox = min(ox0 + p % TW, a.Wout - 1);
-                            const int cc = min(co4, a.Cout - 4);
-                            rs[j] = *reinterpret_cast<const f32x4*>(a.resid + ((size_t)(n * a.Hout + oy) * a.Wout + ox) * a.Cout + cc);
+                            const int oy = min(oy0 + p / TW, aHout - 1), ox = min(ox0 + p % TW, aWout - 1);
+                            const int cc = min(co4, aCout - 4);
+                            rs[j] = *reinterpret_cast<const f32x4*>(residn + (unsigned)(oy * aWout + ox) * (unsigned)aCout + (unsigned)cc);
                         }
                     }
                     {
@@ -373,7 +389,7 @@ __global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI)) void k_conv(const Co
                         if (a.resid) v += rs[j];
                         if (cv4 && oy < a.Hout && ox < a.Wout) {
                             if (!(dbg & 8))
-                                *reinterpret_cast<f32x4*>(a.out + ((size_t)(n * a.Hout + oy) * a.Wout + ox) * a.Cout + co4) = v;
+                                *reinterpret_cast<f32x4*>(outn + (unsigned)(oy * aWout + ox) * (unsigned)aCout + (unsigned)co4) = v;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) { t1[e] += v[e]; t2[e] = fmaf(v[e], v[e], t2[e]); }
                         }
