@@ -207,13 +207,14 @@ __global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI)) void k_conv(const Co
         if (PREC != CCDM_PREC_F32) {
             // skip chunks carry one tap (1x1): only the first NI*128 items are meaningful, the rest re-read them
             const f32x4* wq = reinterpret_cast<const f32x4*>(sk ? a.skip_w : a.w) + ((size_t)(c0 >> 4) * k.ntiles + nt0) * 128;
-            const size_t wtap = (size_t)((sk ? k.cin_pad_skip : k.cin_pad) >> 4) * k.ntiles * 128;
+            const unsigned wtap = (unsigned)((sk ? k.cin_pad_skip : k.cin_pad) >> 4) * k.ntiles * 128;
             const int nb4 = sk ? NI * 128 : NB4;
 #pragma unroll
             for (int i = 0; i < NITEM_B; ++i) {
                 int j = (int)t_ + i * NT;
                 j = j < nb4 ? j : nb4 - 1;            // unconditional load (keeps regB[] in registers)
-                regB[i] = wq[(size_t)(j / (NI * 128)) * wtap + (j % (NI * 128))];
+                regB[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(wq) +
+                                                          (((unsigned)(j / (NI * 128)) * wtap + (unsigned)(j % (NI * 128))) << 4));
             }
         }
     };
@@ -360,7 +361,8 @@ __global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI)) void k_conv(const Co
                             const int p = wave * MI * 32 + j * 8 + prow;
                             const int oy = min(oy0 + p / TW, aHout - 1), ox = min(ox0 + p % TW, aWout - 1);
                             const int cc = min(co4, aCout - 4);
-                            rs[j] = *reinterpret_cast<const f32x4*>(residn + (unsigned)(oy * aWout + ox) * (unsigned)aCout + (unsigned)cc);
+                            rs[j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(residn) +
+                                                                    (((unsigned)(oy * aWout + ox) * (unsigned)aCout + (unsigned)cc) << 2));
                         }
                     }
                     {
@@ -389,7 +391,8 @@ __global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI)) void k_conv(const Co
                         if (a.resid) v += rs[j];
                         if (cv4 && oy < a.Hout && ox < a.Wout) {
                             if (!(dbg & 8))
-                                *reinterpret_cast<f32x4*>(outn + (unsigned)(oy * aWout + ox) * (unsigned)aCout + (unsigned)co4) = v;
+                                *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(outn) +
+                                                          (((unsigned)(oy * aWout + ox) * (unsigned)aCout + (unsigned)co4) << 2)) = v;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) { t1[e] += v[e]; t2[e] = fmaf(v[e], v[e], t2[e]); }
                         }

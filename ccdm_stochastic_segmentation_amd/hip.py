@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(_HERE, "libccdm_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["ccdm_conv.hip", "ccdm_misc.hip", "ccdm_attention.hip", "ccdm_sampler.hip", "ccdm_engine.hip"]
+SOURCES = ["ccdm_conv.hip", "ccdm_misc.hip", "ccdm_attention.hip", "ccdm_sampler.hip", "ccdm_metrics.hip", "ccdm_engine.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
 ACT_NONE, ACT_SILU = 0, 1
@@ -74,6 +74,7 @@ SIGNATURES = {
     "ccdm_time_table": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ccdm_posterior_sample": (C.c_int, [C.POINTER(PostArgs), C.c_void_p]),
+    "ccdm_pairwise_class_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ccdm_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ccdm_onehot_to_xin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ccdm_engine_create": (C.c_void_p, [C.c_void_p]),

@@ -146,6 +146,16 @@ typedef struct ccdm_post_args {
 
 int ccdm_posterior_sample(const ccdm_post_args* a, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * LIDC metrics, device part: for every image and every pair (i, j) of class-index maps
+ * a[img][i], b[img][j], the per-class pixel counts out[img][i][j][k] = {|a==k & b==k|, |a==k | b==k|}.
+ * Replaces the [B,S,S',HW,K] boolean broadcast of `batched_distance` / `iou`
+ * (evaluation/evaluate_lidc_uncertainty.py:27-39); GED and Hungarian-matched IoU follow on the host from the
+ * exact integer counts.
+ * ------------------------------------------------------------------------------------------------- */
+int ccdm_pairwise_class_counts(const uint8_t* a /*dev [B,S,HW]*/, const uint8_t* b /*dev [B,L,HW]*/, int B, int S, int L,
+                               int HW, int K, int32_t* out /*dev [B,S,L,K,2]*/, void* stream);
+
 /* boundary re-layout helpers */
 int ccdm_nchw_to_nhwc(const float* src, float* dst, int N, int C, int HW, int dst_stride, int dst_off, void* stream);
 int ccdm_onehot_to_xin(const uint8_t* idx, float* xin, int N, int HW, int K, int xin_stride, void* stream);

@@ -452,3 +452,38 @@ def forward_denoising(sd: Dict[str, Tensor], cfg: dict, schedule, x: Tensor, con
         if trace is not None:
             trace.append(rec)
     return {"diffusion_out": xt}
+
+
+# ----------------------------------------------------------------------------------------------
+# N1  LIDC metrics (numpy restatement)        evaluation/evaluate_lidc_uncertainty.py:27-73
+# ----------------------------------------------------------------------------------------------
+def metrics_iou(x, y, axis=-1):
+    with np.errstate(divide="ignore", invalid="ignore"):
+        iou_ = (x & y).sum(axis) / (x | y).sum(axis)
+    iou_[np.isnan(iou_)] = 1.
+    return iou_
+
+
+def metrics_batched_distance(x, y):
+    per_class_iou = metrics_iou(x[:, :, None], y[:, None, :], axis=-2)          # exclude background (class 0)
+    return 1 - per_class_iou[..., 1:].mean(-1)
+
+
+def metrics_ged(samples_dist_0, samples_dist_1, num_classes):
+    a = samples_dist_0.reshape(*samples_dist_0.shape[:2], -1)
+    b = samples_dist_1.reshape(*samples_dist_1.shape[:2], -1)
+    eye = np.eye(num_classes)
+    a, b = eye[a].astype(bool), eye[b].astype(bool)
+    cross = np.mean(metrics_batched_distance(a, b), axis=(1, 2))
+    d0 = np.mean(metrics_batched_distance(a, a), axis=(1, 2))
+    d1 = np.mean(metrics_batched_distance(b, b), axis=(1, 2))
+    return 2 * cross - d0 - d1, d0, d1
+
+
+def metrics_hungarian_iou(samples_dist_0, samples_dist_1, num_classes):
+    from scipy.optimize import linear_sum_assignment
+    a = samples_dist_0.reshape(*samples_dist_0.shape[:2], -1)
+    b = samples_dist_1.reshape(*samples_dist_1.shape[:2], -1)
+    eye = np.eye(num_classes)
+    cost = metrics_batched_distance(eye[a].astype(bool), eye[b].astype(bool))
+    return [(1 - cost[i])[linear_sum_assignment(cost[i])].mean() for i in range(a.shape[0])]

@@ -456,3 +456,63 @@ def test_full_size_properties_c2(U, lidc_model):
     b = model(x[16:32], image[16:32], t=torch.as_tensor(10006))["diffusion_out"]
     model.sample_offset = 0
     assert torch.equal(b, a[16:32])
+
+
+# ------------------------------------------------------------------------------------------ N1 metrics
+@pytest.mark.parametrize("tag", ["k2", "k2_empty", "k5"])
+def test_lidc_metrics_device_bit_exact(U, golden, tag):
+    """GED / diversity / Hungarian-matched IoU from the device pair-count kernel == the reference's numpy, bit for bit."""
+    from tests.test_oracle_golden import _metric_case
+    from ccdm_stochastic_segmentation_amd import metrics as M
+    g = golden["g10_lidc_metrics"]
+    K, lab, smp = _metric_case(g, tag)
+    lab_d, smp_d = torch.from_numpy(lab).to(U.DEV), torch.from_numpy(smp).to(U.DEV)
+    ged, de, ds = M.calc_batched_generalised_energy_distance(lab_d, smp_d, K)
+    assert np.array_equal(ged, g[f"{tag}_ged"]) and np.array_equal(de, g[f"{tag}_div_experts"]) and np.array_equal(ds, g[f"{tag}_div_samples"])
+    lcm = np.lcm(smp.shape[1], lab.shape[1])
+    hm = M.batched_hungarian_matching(lab_d.repeat_interleave(lcm // lab.shape[1], 1), smp_d.repeat_interleave(lcm // smp.shape[1], 1), K)
+    assert np.array_equal(np.array(hm), g[f"{tag}_hm_iou"])
+    counts = M.pairwise_class_counts(lab_d, smp_d, K)
+    eye = np.eye(K, dtype=bool)
+    a, b = eye[lab.reshape(*lab.shape[:2], -1)], eye[smp.reshape(*smp.shape[:2], -1)]
+    assert np.array_equal(counts[..., 0], (a[:, :, None] & b[:, None, :]).sum(-2))
+    assert np.array_equal(counts[..., 1], (a[:, :, None] | b[:, None, :]).sum(-2))
+
+
+def test_ddpm_eval_entry_point_on_synthetic_lidc(U, capsys):
+    """`python ddpm_eval.py params_eval_synthetic.yml`: the reference's entry point + params keys, end to end on the GPU
+    (SyntheticLIDC stands in for data_lidc.hdf5; synthetic weights stand in for the checkpoint)."""
+    import json
+    import os
+    import ddpm_eval
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cwd = os.getcwd()
+    os.chdir(root)
+    try:
+        ddpm_eval.main(["ddpm_eval.py", "params_eval_synthetic.yml"])
+    finally:
+        os.chdir(cwd)
+    res = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert res["images"] == 4 and res["evaluations"] == [1, 2]
+    assert all(np.isfinite(res["GED"])) and all(0 <= v <= 2 for v in res["GED"])
+    assert all(0 <= v <= 1 for v in res["HM_IoU"]) and 0 <= res["mIoU"] <= 1
+    assert res["diversity_samples"][0] == 0.0            # one sample per image: no diversity
+
+
+def test_checkpoint_file_roundtrip(U, tmp_path, lidc_model):
+    """An ignite-style checkpoint dict written with torch.save loads through load_checkpoint and gives the same output."""
+    from ccdm_stochastic_segmentation_amd.evaluation import load_checkpoint
+    model, sd = lidc_model
+    path = tmp_path / "ckpt.pt"
+    torch.save({"model": sd, "average_model": sd, "optimizer": {"state": {}, "param_groups": []}}, path)
+    m2 = build_model(250, "cosine", {"s": 0.008}, [(1, 128, 128), (2, 128, 128)], (1, 128, 128), "unet_openai", LIDC_BP,
+                     "datasets.lidc", "confidence", None).to("cuda:0").eval()
+    m2.prec = model.prec
+    load_checkpoint(m2, str(path))
+    rng = np.random.default_rng(3)
+    image = torch.from_numpy(rng.uniform(-1, 1, (1, 1, 128, 128)).astype(np.float32)).to(U.DEV)
+    x = O.one_hot_bchw(torch.from_numpy(rng.integers(0, 2, (1, 128, 128))), 2).to(U.DEV)
+    t = torch.full((1,), 50.0)
+    a = model(x, image, t=t, validation=True)["diffusion_out"]
+    b = m2(x, image, t=t, validation=True)["diffusion_out"]
+    assert torch.equal(a, b)

@@ -216,3 +216,24 @@ def test_philox_known_answer():
     e = O.philox_exponential(seed=123, step=5, sample0=0, n=2, hw=64, k=20)
     assert e.shape == (2, 64, 20) and np.isfinite(e).all() and (e > 0).all()
     assert abs(e.mean() - 1.0) < 0.1
+
+
+def _metric_case(g, tag):
+    K, B, S, L, h, w = (int(v) for v in g[f"{tag}_shape"])
+    rng = np.random.default_rng(int(g[f"{tag}_seed"]))
+    lab = rng.integers(0, K, (B, L, h, w))
+    smp = rng.integers(0, K, (B, S, h, w))
+    if tag == "k2_empty":
+        lab[0] = 0; smp[0, :2] = 0; smp[1] = 0
+    return K, lab, smp
+
+
+@pytest.mark.parametrize("tag", ["k2", "k2_empty", "k5"])
+def test_g10_lidc_metrics(golden, tag):
+    g = golden["g10_lidc_metrics"]
+    K, lab, smp = _metric_case(g, tag)
+    ged, de, ds = O.metrics_ged(lab, smp, K)
+    assert np.array_equal(ged, g[f"{tag}_ged"]) and np.array_equal(de, g[f"{tag}_div_experts"]) and np.array_equal(ds, g[f"{tag}_div_samples"])
+    lcm = np.lcm(smp.shape[1], lab.shape[1])
+    hm = O.metrics_hungarian_iou(np.repeat(lab, lcm // lab.shape[1], 1), np.repeat(smp, lcm // smp.shape[1], 1), K)
+    assert np.array_equal(np.array(hm), g[f"{tag}_hm_iou"])
