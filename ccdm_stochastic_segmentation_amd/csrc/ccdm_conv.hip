@@ -29,12 +29,19 @@
 
 namespace ccdm {
 
+// phase timeline of one block (ablation bit 16 of prec; read back with ccdm_debug_read_timeline)
+__device__ unsigned long long g_timeline[1024];
+#define CCDM_STAMP(slot) do { if ((dbg & 16) && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && tid == 0 && tl < 1020) \
+        g_timeline[tl++] = ((unsigned long long)(slot) << 56) | (__builtin_amdgcn_s_memtime() & 0x00ffffffffffffffull); } while (0)
+
 // F32  : CK = 32 channels per chunk; LDS pixel = 33 floats (odd stride: conflict-free column reads).
 // F16X3: CK = 16 channels per chunk; LDS pixel = 16 hi halfs | 16 lo halfs | 16 B pad = 80 B = 20 dwords:
 //        the 16 pixels of a ds_read_b128 lane group land on 16 disjoint 4-bank slots (20*p mod 64).
-template <int PREC> struct Lds {
-    static constexpr int CK = PREC == CCDM_PREC_F32 ? 32 : 16;
-    static constexpr int PIXB = PREC == CCDM_PREC_F32 ? 33 * 4 : 80;
+//        Small-spatial stages (few pixels, many channels) take CK = 32 per chunk instead (pixel = 32 hi | 32 lo | pad
+//        = 144 B = 36 dwords, also conflict-free): half as many barrier/latency round trips per tile.
+template <int PREC, int CKT> struct Lds {
+    static constexpr int CK = CKT;
+    static constexpr int PIXB = PREC == CCDM_PREC_F32 ? 33 * 4 : CKT * 4 + 16;
 };
 
 __device__ __forceinline__ float silu_fast(float x) {
@@ -88,12 +95,16 @@ __device__ __forceinline__ void compute_gn_affine(const ccdm_conv_args& a, int n
 
 // register budget: >= 3 waves per SIMD (<= 168 VGPRs) when the accumulator tile is small — matches the 3 blocks
 // per CU the LDS footprint (A tile 27 KB + B chunk 18 KB) admits
-constexpr int min_waves(int mi, int ni) { return mi * ni <= 2 ? 3 : (mi * ni <= 4 ? 2 : 1); }
+constexpr int min_waves(int mi, int ni, int prec, int ckt) {
+    if (prec != CCDM_PREC_F32 && ckt == 32) return 2;      // small-spatial variant: few blocks per CU anyway, take the registers
+    return mi * ni <= 2 ? 3 : (mi * ni <= 4 ? 2 : 1);
+}
 
-template <int PREC, int KS, int STRIDE, int TH, int TW, int WAVES, int MI, int NI>
-__global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI)) void k_conv(const ConvK k) {
+template <int PREC, int CKT, int KS, int STRIDE, int TH, int TW, int WAVES, int MI, int NI>
+__global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI, PREC, CKT)) void k_conv(const ConvK k) {
     constexpr int NT = WAVES * 64;
-    constexpr int CK = Lds<PREC>::CK, PIXB = Lds<PREC>::PIXB;
+    constexpr int CK = Lds<PREC, CKT>::CK, PIXB = Lds<PREC, CKT>::PIXB;
+    constexpr int KST = CK / 16;                                  // F16X3: 16-channel MFMA k-steps per chunk
     constexpr int PAD = KS / 2;
     constexpr int HHt = (TH - 1) * STRIDE + KS, HWt = (TW - 1) * STRIDE + KS, HP = HHt * HWt;
     constexpr int QPP = CK / 4;                                   // float4 items per halo pixel
@@ -102,7 +113,7 @@ __global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI)) void k_conv(const Co
     static_assert(NT % QPP == 0, "channel quad must be item-invariant");
     constexpr int A_BYTES = (HP * PIXB + 15) / 16 * 16;
     // F16X3: the chunk's B fragments, [tap][ni][hi|lo][64 lanes] x 16 B, staged through registers like the halo
-    constexpr int NB4 = PREC == CCDM_PREC_F32 ? 0 : KS * KS * NI * 128;
+    constexpr int NB4 = PREC == CCDM_PREC_F32 ? 0 : KS * KS * KST * NI * 128;
     constexpr int NITEM_B = (NB4 + NT - 1) / NT;
 
     const ccdm_conv_args& a = k.a;
@@ -205,16 +216,19 @@ __global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI)) void k_conv(const Co
             if (hx >= (unsigned)HWt) { hx -= HWt; hy += 1; }
         }
         if (PREC != CCDM_PREC_F32) {
-            // skip chunks carry one tap (1x1): only the first NI*128 items are meaningful, the rest re-read them
+            // B chunk: [tap][k-step][ni][hi|lo][lane]; skip chunks carry one tap (1x1): only the first KST*NI*128 items
+            // are meaningful there, the rest re-read the last one
             const f32x4* wq = reinterpret_cast<const f32x4*>(sk ? a.skip_w : a.w) + ((size_t)(c0 >> 4) * k.ntiles + nt0) * 128;
             const unsigned wtap = (unsigned)((sk ? k.cin_pad_skip : k.cin_pad) >> 4) * k.ntiles * 128;
-            const int nb4 = sk ? NI * 128 : NB4;
+            const unsigned wks = (unsigned)k.ntiles * 128;
+            const int nb4 = sk ? KST * NI * 128 : NB4;
 #pragma unroll
             for (int i = 0; i < NITEM_B; ++i) {
                 int j = (int)t_ + i * NT;
                 j = j < nb4 ? j : nb4 - 1;            // unconditional load (keeps regB[] in registers)
+                const unsigned ts = (unsigned)j / (NI * 128), rem = (unsigned)j % (NI * 128);
                 regB[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(wq) +
-                                                          (((unsigned)(j / (NI * 128)) * wtap + (unsigned)(j % (NI * 128))) << 4));
+                                                          (((ts / KST) * wtap + (ts % KST) * wks + rem) << 4));
             }
         }
     };
@@ -253,7 +267,7 @@ __global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI)) void k_conv(const Co
                     lo[2] = (_Float16)(v.z - (float)hi[2]); lo[3] = (_Float16)(v.w - (float)hi[3]);
                     char* d = halo_b + hp * PIXB + 8 * q;
                     *reinterpret_cast<f16x4*>(d) = hi;
-                    *reinterpret_cast<f16x4*>(d + 32) = lo;
+                    *reinterpret_cast<f16x4*>(d + 2 * CK) = lo;
                 }
             }
         }
@@ -267,6 +281,8 @@ __global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI)) void k_conv(const Co
     };
 
     f32x16 acc[MI][NI];
+    int tl = 0;
+    CCDM_STAMP(1);
     if (n_iter > 0) issue(0);
     for (int it = 0; it < n_iter; ++it) {
         const int chunk = it % nchunk;
@@ -278,11 +294,16 @@ __global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI)) void k_conv(const Co
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
         }
+        CCDM_STAMP(2);
         __syncthreads();          // previous MFMA phase has finished reading LDS (and ab[] is visible)
+        CCDM_STAMP(3);
         if (!(dbg & 2)) commit(it);
+        CCDM_STAMP(4);
         __syncthreads();
+        CCDM_STAMP(5);
         if (!(dbg & 4)) issue(it + 1 < n_iter ? it + 1 : it);    // next tile-chunk's HBM reads fly during the MFMA phase (the last one re-reads its own: harmless, branch-free)
 
+        CCDM_STAMP(6);
         const bool skc = chunk >= nchunk_main;                   // uniform
         const int c0 = (skc ? chunk - nchunk_main : chunk) * CK;
         if (dbg & 1) {
@@ -318,27 +339,31 @@ __global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI)) void k_conv(const Co
                 if (skc && tap != (KS * KS) / 2) continue;       // skip segment: centre tap only, staged as B slot 0
                 const int bt = skc ? 0 : tap;
                 const int toff = ((tap / KS) * HWt + (tap % KS)) * PIXB;
-                f16x8 ah[MI], al[MI];
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) {
-                    const char* p = halo_b + base[mi] + toff;
-                    ah[mi] = *reinterpret_cast<const f16x8*>(p);
-                    al[mi] = *reinterpret_cast<const f16x8*>(p + 32);
-                }
+                for (int ks = 0; ks < KST; ++ks) {
+                    f16x8 ah[MI], al[MI];
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    const f16x8 bh = bq[(bt * NI + ni) * 128];
-                    const f16x8 bl = bq[(bt * NI + ni) * 128 + 64];
+                    for (int mi = 0; mi < MI; ++mi) {
+                        const char* p = halo_b + base[mi] + toff + 32 * ks;
+                        ah[mi] = *reinterpret_cast<const f16x8*>(p);
+                        al[mi] = *reinterpret_cast<const f16x8*>(p + 2 * CK);
+                    }
 #pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh, acc[mi][ni], 0, 0, 0);
+                    for (int ni = 0; ni < NI; ++ni) {
+                        const f16x8 bh = bq[((bt * KST + ks) * NI + ni) * 128];
+                        const f16x8 bl = bq[((bt * KST + ks) * NI + ni) * 128 + 64];
 #pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl, acc[mi][ni], 0, 0, 0);
+                        for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh, acc[mi][ni], 0, 0, 0);
 #pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh, acc[mi][ni], 0, 0, 0);
+                        for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl, acc[mi][ni], 0, 0, 0);
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh, acc[mi][ni], 0, 0, 0);
+                    }
                 }
             }
         }
 
+        CCDM_STAMP(7);
         if (chunk == nchunk - 1) {
             // ---- epilogue: (x 2^-e) + bias (+ emb) (+ residual), store NHWC, accumulate output statistics ----
             const int tile = slice + (it / nchunk) * k.slices;
@@ -438,6 +463,8 @@ __global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI)) void k_conv(const Co
         }
     }
 
+    CCDM_STAMP(8);
+    if ((dbg & 16) && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && tid == 0) g_timeline[1023] = tl;
     if (a.out_stats) {
         // fold the lanes that hold the same channel, then the block's waves; fixed order everywhere
         __syncthreads();
@@ -484,35 +511,53 @@ __global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI)) void k_conv(const Co
 }
 
 // ---------------------------------------------------------------------------------------------------
-template <int PREC, int KS, int STRIDE, int TH, int TW, int WAVES, int MI>
+// chunk width of the F16X3 path: 32 channels for the small-spatial geometries when the channel counts allow it
+static int chunk_ck(const ccdm_conv_args& a, const ConvGeo& g) {
+    if ((a.prec & 255) == CCDM_PREC_F32) return 32;
+    const int C = a.C0 + a.C1, SC = a.SC0 + a.SC1;
+    const bool ok32 = g.TW < 32 && a.stride == 1 && C % 32 == 0 && (a.C1 == 0 || a.C0 % 32 == 0) &&
+                      (!a.skip0 || (SC % 32 == 0 && (a.SC1 == 0 || a.SC0 % 32 == 0)));
+    return ok32 ? 32 : 16;
+}
+
+template <int PREC, int CKT, int KS, int STRIDE, int TH, int TW, int WAVES, int MI>
 static int launch_ni(const ConvK& k, int NI, dim3 grid, size_t lds, hipStream_t s) {
     dim3 block(WAVES * 64);
+    if (CKT == 32 && PREC != CCDM_PREC_F32) {       // small-spatial CK=32 variant always runs one n-tile per block
+        hipLaunchKernelGGL((k_conv<PREC, CKT, KS, STRIDE, TH, TW, WAVES, MI, 1>), grid, block, lds, s, k);
+        return 0;
+    }
     switch (NI) {
-        case 1: hipLaunchKernelGGL((k_conv<PREC, KS, STRIDE, TH, TW, WAVES, MI, 1>), grid, block, lds, s, k); break;
-        case 2: hipLaunchKernelGGL((k_conv<PREC, KS, STRIDE, TH, TW, WAVES, MI, 2>), grid, block, lds, s, k); break;
-        case 3: hipLaunchKernelGGL((k_conv<PREC, KS, STRIDE, TH, TW, WAVES, MI, 3>), grid, block, lds, s, k); break;
-        case 4: hipLaunchKernelGGL((k_conv<PREC, KS, STRIDE, TH, TW, WAVES, MI, 4>), grid, block, lds, s, k); break;
+        case 1: hipLaunchKernelGGL((k_conv<PREC, CKT, KS, STRIDE, TH, TW, WAVES, MI, 1>), grid, block, lds, s, k); break;
+        case 2: hipLaunchKernelGGL((k_conv<PREC, CKT, KS, STRIDE, TH, TW, WAVES, MI, 2>), grid, block, lds, s, k); break;
+        case 3: hipLaunchKernelGGL((k_conv<PREC, CKT, KS, STRIDE, TH, TW, WAVES, MI, 3>), grid, block, lds, s, k); break;
+        case 4: hipLaunchKernelGGL((k_conv<PREC, CKT, KS, STRIDE, TH, TW, WAVES, MI, 4>), grid, block, lds, s, k); break;
         default: return fail("conv: bad NI %d", NI);
     }
     return 0;
 }
 
 template <int PREC, int KS>
-static int launch_geo(const ConvK& k, const ConvGeo& g, int NI, dim3 grid, size_t lds, hipStream_t s) {
-    if (k.a.stride == 2) return launch_ni<PREC, KS, 2, 8, 8, 2, 1>(k, NI, grid, lds, s);
-    if (g.TW == 32) return launch_ni<PREC, KS, 1, 8, 32, 4, 2>(k, NI, grid, lds, s);
-    if (g.TW == 16) return launch_ni<PREC, KS, 1, 8, 16, 4, 1>(k, NI, grid, lds, s);
-    return launch_ni<PREC, KS, 1, 8, 8, 2, 1>(k, NI, grid, lds, s);
+static int launch_geo(const ConvK& k, const ConvGeo& g, int NI, int ck, dim3 grid, size_t lds, hipStream_t s) {
+    constexpr int CK0 = PREC == CCDM_PREC_F32 ? 32 : 16;
+    if (k.a.stride == 2) return launch_ni<PREC, CK0, KS, 2, 8, 8, 2, 1>(k, NI, grid, lds, s);
+    if (g.TW == 32) return launch_ni<PREC, CK0, KS, 1, 8, 32, 4, 2>(k, NI, grid, lds, s);
+    if (PREC != CCDM_PREC_F32 && ck == 32) {
+        if (g.TW == 16) return launch_ni<PREC, 32, KS, 1, 8, 16, 4, 1>(k, NI, grid, lds, s);
+        return launch_ni<PREC, 32, KS, 1, 8, 8, 2, 1>(k, NI, grid, lds, s);
+    }
+    if (g.TW == 16) return launch_ni<PREC, CK0, KS, 1, 8, 16, 4, 1>(k, NI, grid, lds, s);
+    return launch_ni<PREC, CK0, KS, 1, 8, 8, 2, 1>(k, NI, grid, lds, s);
 }
 
 template <int PREC>
-static int launch_prec(const ConvK& k, const ConvGeo& g, int NI, dim3 grid, size_t lds, hipStream_t s) {
+static int launch_prec(const ConvK& k, const ConvGeo& g, int NI, int ck, dim3 grid, size_t lds, hipStream_t s) {
 #ifdef CCDM_EXPERIMENT   // compile one instantiation only (register/ISA experiments)
-    hipLaunchKernelGGL((k_conv<CCDM_PREC_F16X3, 3, 1, 8, 32, 4, 2, 1>), grid, dim3(256), lds, s, k);
+    hipLaunchKernelGGL((k_conv<CCDM_PREC_F16X3, CCDM_EXPERIMENT_CK, 3, 1, CCDM_EXPERIMENT_GEO, 1>), grid, dim3(256), lds, s, k);
     return 0;
 #else
-    if (k.a.ksize == 3) return launch_geo<PREC, 3>(k, g, NI, grid, lds, s);
-    return launch_geo<PREC, 1>(k, g, NI, grid, lds, s);
+    if (k.a.ksize == 3) return launch_geo<PREC, 3>(k, g, NI, ck, grid, lds, s);
+    return launch_geo<PREC, 1>(k, g, NI, ck, grid, lds, s);
 #endif
 }
 
@@ -583,9 +628,10 @@ int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
     k.wscale = reinterpret_cast<const float*>(static_cast<const char*>(a.w) + packed_frag_bytes(a.Cout, C, a.ksize, prec));
     if (a.out_stats) CCDM_REQUIRE(a.out_slices == k.slices, "conv: out_slices %d != %d", a.out_slices, k.slices);
     const int HP = ((g.TH - 1) * a.stride + a.ksize) * ((g.TW - 1) * a.stride + a.ksize);
-    size_t lds = (size_t)HP * (prec == CCDM_PREC_F32 ? Lds<CCDM_PREC_F32>::PIXB : Lds<CCDM_PREC_F16X3>::PIXB);
+    const int ck = chunk_ck(a, g);
+    size_t lds = (size_t)HP * (prec == CCDM_PREC_F32 ? 33 * 4 : ck * 4 + 16);
     lds = (lds + 15) / 16 * 16;
-    if (prec != CCDM_PREC_F32) lds += (size_t)a.ksize * a.ksize * NI * 128 * 16;     // staged B chunk
+    if (prec != CCDM_PREC_F32) lds += (size_t)a.ksize * a.ksize * (ck / 16) * NI * 128 * 16;     // staged B chunk
     const size_t red = (size_t)g.waves * NI * 32 * 16;
     if (lds < red) lds = red;
     const size_t epi = (size_t)g.waves * g.MI * 32 * 36 * 4;        // epilogue transpose buffer (wave-private rows)
@@ -593,8 +639,8 @@ int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
     if (a.stats0) lds += (size_t)C * 8;
     CCDM_REQUIRE(lds <= 160 * 1024, "conv: LDS %zu too large", lds);
     dim3 grid(a.N * k.slices, k.ntiles / NI);
-    const int rc = prec == CCDM_PREC_F32 ? launch_prec<CCDM_PREC_F32>(k, g, NI, grid, lds, s)
-                                           : launch_prec<CCDM_PREC_F16X3>(k, g, NI, grid, lds, s);
+    const int rc = prec == CCDM_PREC_F32 ? launch_prec<CCDM_PREC_F32>(k, g, NI, ck, grid, lds, s)
+                                           : launch_prec<CCDM_PREC_F16X3>(k, g, NI, ck, grid, lds, s);
     if (rc) return rc;
     CCDM_CHECK_LAUNCH("conv");
     return 0;
@@ -605,6 +651,13 @@ int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
 extern "C" int ccdm_conv_slices(int Hout, int Wout, int stride, int ksize) {
     (void)ksize;
     return ccdm::conv_slices(Hout, Wout, stride);
+}
+
+extern "C" int ccdm_debug_read_timeline(unsigned long long* host, int n) {
+    if (!host || n <= 0 || n > 1024) return ccdm::fail("debug_read_timeline: bad args");
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(ccdm::g_timeline), (size_t)n * 8, 0, hipMemcpyDeviceToHost) != hipSuccess)
+        return ccdm::fail("debug_read_timeline: copy failed");
+    return 0;
 }
 
 extern "C" int ccdm_conv2d(const ccdm_conv_args* a, void* stream) {

@@ -75,6 +75,7 @@ SIGNATURES = {
                                   C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ccdm_posterior_sample": (C.c_int, [C.POINTER(PostArgs), C.c_void_p]),
     "ccdm_pairwise_class_counts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "ccdm_debug_read_timeline": (C.c_int, [C.c_void_p, C.c_int]),
     "ccdm_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ccdm_onehot_to_xin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ccdm_engine_create": (C.c_void_p, [C.c_void_p]),

@@ -156,6 +156,9 @@ int ccdm_posterior_sample(const ccdm_post_args* a, void* stream);
 int ccdm_pairwise_class_counts(const uint8_t* a /*dev [B,S,HW]*/, const uint8_t* b /*dev [B,L,HW]*/, int B, int S, int L,
                                int HW, int K, int32_t* out /*dev [B,S,L,K,2]*/, void* stream);
 
+/* debugging aid: phase timestamps (s_memtime) one block of the last conv launched with ablation bit 16 recorded */
+int ccdm_debug_read_timeline(unsigned long long* host, int n);
+
 /* boundary re-layout helpers */
 int ccdm_nchw_to_nhwc(const float* src, float* dst, int N, int C, int HW, int dst_stride, int dst_off, void* stream);
 int ccdm_onehot_to_xin(const uint8_t* idx, float* xin, int N, int HW, int K, int xin_stride, void* stream);

@@ -74,9 +74,32 @@ def run(prec, shape, iters=20, dbg=0):
     return ms, flops / ms / 1e9, byts / ms / 1e6
 
 
+def timeline(prec, shape):
+    """Phase durations (cycles) of one mid-grid block: stamps 2..7 per iteration = loop top | barrier A | commit | barrier B |
+    issue | MFMA phase | (epilogue)."""
+    run(prec, shape, iters=1, dbg=16)
+    lib = hip.load()
+    buf = (C.c_ulonglong * 1024)()
+    hip.check(lib.ccdm_debug_read_timeline(buf, 1024))
+    n = int(buf[1023])
+    ev = [(int(buf[i]) >> 56, int(buf[i]) & ((1 << 56) - 1)) for i in range(min(n, 1020))]
+    names = {1: "start", 2: "top(prev phase end)", 3: "barrierA", 4: "commit", 5: "barrierB", 6: "issue", 7: "mfma", 8: "end"}
+    t0 = ev[0][1]
+    prev = t0
+    out = []
+    for slot, t in ev[1:]:
+        out.append(f"{names.get(slot, slot)}+{t - prev}")
+        prev = t
+    print(f"timeline total {prev - t0} cycles (100 MHz-ish s_memtime ticks): " + " ".join(out[:64]))
+
+
 if __name__ == "__main__":
     precs = [hip.PREC_F16X3] if len(sys.argv) < 2 else [int(v) for v in sys.argv[1].split(",")]
     only = int(sys.argv[2]) if len(sys.argv) > 2 else None
+    if os.environ.get("TIMELINE"):
+        for i in [int(v) for v in os.environ["TIMELINE"].split(",")]:
+            print(SHAPES[i]); timeline(precs[0], SHAPES[i])
+        sys.exit(0)
     for prec in precs:
         total = 0.0
         print(f"--- prec={prec} N={N}")
