@@ -95,14 +95,20 @@ __device__ __forceinline__ void compute_gn_affine(const ccdm_conv_args& a, int n
 
 // register budget: >= 3 waves per SIMD (<= 168 VGPRs) when the accumulator tile is small — matches the 3 blocks
 // per CU the LDS footprint (A tile 27 KB + B chunk 18 KB) admits
-constexpr int min_waves(int mi, int ni, int prec, int ckt) {
+constexpr int min_waves(int mi, int ni, int prec, int ckt, int threads) {
+    if (threads > 512) return 3;                           // 12-wave blocks (tap-split 8x16 tiles): 3 waves per SIMD
     if (prec != CCDM_PREC_F32 && ckt == 32) return 2;      // small-spatial variant: few blocks per CU anyway, take the registers
     return mi * ni <= 2 ? 3 : (mi * ni <= 4 ? 2 : 1);
 }
 
-template <int PREC, int CKT, int KS, int STRIDE, int TH, int TW, int WAVES, int MI, int NI>
-__global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI, PREC, CKT)) void k_conv(const ConvK k) {
-    constexpr int NT = WAVES * 64;
+// KSP > 1 (small-spatial 3x3 convs): KSP wave groups share one staged tile and split the kernel rows between them
+// (group r multiplies only taps (r, *)); their partial accumulators meet in the epilogue's LDS buffer.  A few-pixel
+// stage has too few tiles to fill the chip with pixel parallelism alone — this triples the waves per tile and cuts
+// the per-wave MFMA chain to a third.
+template <int PREC, int CKT, int KS, int STRIDE, int TH, int TW, int WAVES, int MI, int NI, int KSP = 1>
+__global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVES * KSP * 64)) void k_conv(const ConvK k) {
+    constexpr int NT = WAVES * KSP * 64;
+    static_assert(KSP == 1 || KSP == KS, "tap split is by kernel row");
     constexpr int CK = Lds<PREC, CKT>::CK, PIXB = Lds<PREC, CKT>::PIXB;
     constexpr int KST = CK / 16;                                  // F16X3: 16-channel MFMA k-steps per chunk
     constexpr int PAD = KS / 2;
@@ -125,7 +131,8 @@ __global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI, PREC, CKT)) void k_co
     f32x4* ldsB = reinterpret_cast<f32x4*>(halo_b + A_BYTES);      // native vector type: HIP's float4 struct defeats SROA here
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave_all % WAVES, krow = wave_all / WAVES;       // pixel sub-tile owner, kernel row (KSP > 1)
     // XCD-aware mapping: block b runs on XCD b % 8 — give each XCD a contiguous range of (sample, slice)
     // pairs so the slices of a sample (shared halo rows, shared statistics) meet in one L2.
     int bid = blockIdx.x;
@@ -162,7 +169,7 @@ __global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI, PREC, CKT)) void k_co
         for (int j = 0; j < 4; ++j) { s1[ni][j] = 0.f; s2[ni][j] = 0.f; }
     const bool fast_epi = (a.Cout & 3) == 0;       // uniform: float4 rows through an LDS transpose
     constexpr int EPS = 36;                        // floats per pixel row of the transpose buffer (16-B aligned rows)
-    float* epi = reinterpret_cast<float*>(halo_b) + wave * (MI * 32 * EPS);
+    float* epi = reinterpret_cast<float*>(halo_b) + wave_all * (MI * 32 * EPS);      // [krow][wave][MI*32][EPS]
 
     const int ntile_sp = k.tiles_x * k.tiles_y;
     const int nchunk_main = k.cin_pad / CK;
@@ -337,6 +344,7 @@ __global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI, PREC, CKT)) void k_co
 #pragma unroll
             for (int tap = 0; tap < KS * KS; ++tap) {
                 if (skc && tap != (KS * KS) / 2) continue;       // skip segment: centre tap only, staged as B slot 0
+                if (KSP > 1 && tap / KS != krow) continue;       // tap split: this wave group owns kernel row `krow`
                 const int bt = skc ? 0 : tap;
                 const int toff = ((tap / KS) * HWt + (tap % KS)) * PIXB;
 #pragma unroll
@@ -377,12 +385,14 @@ __global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI, PREC, CKT)) void k_co
                 const int cq = lane_ & 7, prow = lane_ >> 3;
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
+                    if (KSP > 1 && ni > 0) __syncthreads();        // the partials of the previous n-tile have been consumed
                     const int co4 = (nt0 + ni) * 32 + 4 * cq;
                     const bool cv4 = co4 < a.Cout;
                     f32x4 rs[MI * 4];
                     if (a.resid) {
 #pragma unroll
                         for (int j = 0; j < MI * 4; ++j) {
+                            if (KSP > 1 && j % KSP != krow) continue;
                             const int p = wave * MI * 32 + j * 8 + prow;
                             const int oy = min(oy0 + p / TW, aHout - 1), ox = min(ox0 + p % TW, aWout - 1);
                             const int cc = min(co4, aCout - 4);
@@ -394,9 +404,11 @@ __global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI, PREC, CKT)) void k_co
                         const int co = (nt0 + ni) * 32 + (lane_ & 31);
                         float add = 0.f, wsc = 1.0f;
                         if (co < a.Cout) {
-                            add = a.bias ? a.bias[co] : 0.f;
+                            if (krow == 0) {                        // bias (+emb) enters once, through row group 0's partial
+                                add = a.bias ? a.bias[co] : 0.f;
+                                if (a.emb_off >= 0) add += a.emb_table[(size_t)emb_row * a.emb_stride + a.emb_off + co];
+                            }
                             if (PREC != CCDM_PREC_F32) wsc = k.wscale[co];
-                            if (a.emb_off >= 0) add += a.emb_table[(size_t)emb_row * a.emb_stride + a.emb_off + co];
                         }
 #pragma unroll
                         for (int mi = 0; mi < MI; ++mi)
@@ -406,13 +418,19 @@ __global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI, PREC, CKT)) void k_co
                                 epi[pl * EPS + (lane_ & 31)] = (PREC == CCDM_PREC_F32 ? acc[mi][ni][r] : acc[mi][ni][r] * wsc) + add;
                             }
                     }
+                    if (KSP > 1) __syncthreads();                  // all row groups' partials are in LDS
+                    const float* epi0 = reinterpret_cast<const float*>(halo_b) + wave * (MI * 32 * EPS);   // row group 0 of this sub-tile
                     float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int j = 0; j < MI * 4; ++j) {
+                        if (KSP > 1 && j % KSP != krow) continue;   // the row groups share the final pass
                         const int pl = j * 8 + prow;
                         const int p = wave * MI * 32 + pl;
                         const int oy = oy0 + p / TW, ox = ox0 + p % TW;
-                        f32x4 v = *reinterpret_cast<const f32x4*>(epi + pl * EPS + 4 * cq);
+                        f32x4 v = *reinterpret_cast<const f32x4*>(epi0 + pl * EPS + 4 * cq);
+#pragma unroll
+                        for (int g = 1; g < KSP; ++g)               // fixed order: row 0 + row 1 + row 2
+                            v += *reinterpret_cast<const f32x4*>(epi0 + g * (WAVES * MI * 32 * EPS) + pl * EPS + 4 * cq);
                         if (a.resid) v += rs[j];
                         if (cv4 && oy < a.Hout && ox < a.Wout) {
                             if (!(dbg & 8))
@@ -468,7 +486,7 @@ __global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI, PREC, CKT)) void k_co
     if (a.out_stats) {
         // fold the lanes that hold the same channel, then the block's waves; fixed order everywhere
         __syncthreads();
-        double* red = reinterpret_cast<double*>(halo_b);     // [WAVES][NI][32][2]
+        double* red = reinterpret_cast<double*>(halo_b);     // [WAVES*KSP][NI][32][2]
         if (fast_epi) {
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
@@ -478,8 +496,8 @@ __global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI, PREC, CKT)) void k_co
 #pragma unroll
                     for (int off = 8; off < 64; off <<= 1) { v1 += __shfl_xor(v1, off); v2 += __shfl_xor(v2, off); }
                     if (lane < 8) {
-                        red[((wave * NI + ni) * 32 + 4 * lane + e) * 2 + 0] = v1;
-                        red[((wave * NI + ni) * 32 + 4 * lane + e) * 2 + 1] = v2;
+                        red[((wave_all * NI + ni) * 32 + 4 * lane + e) * 2 + 0] = v1;
+                        red[((wave_all * NI + ni) * 32 + 4 * lane + e) * 2 + 1] = v2;
                     }
                 }
         } else {
@@ -488,8 +506,8 @@ __global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI, PREC, CKT)) void k_co
                 const double m1 = (double)s1[ni][0], m2 = (double)s2[ni][0];
                 const double o1 = __shfl_xor(m1, 32), o2 = __shfl_xor(m2, 32);
                 if (lane < 32) {
-                    red[((wave * NI + ni) * 32 + lane) * 2 + 0] = m1 + o1;
-                    red[((wave * NI + ni) * 32 + lane) * 2 + 1] = m2 + o2;
+                    red[((wave_all * NI + ni) * 32 + lane) * 2 + 0] = m1 + o1;
+                    red[((wave_all * NI + ni) * 32 + lane) * 2 + 1] = m2 + o2;
                 }
             }
         }
@@ -497,7 +515,7 @@ __global__ __launch_bounds__(WAVES * 64, min_waves(MI, NI, PREC, CKT)) void k_co
         for (int i = tid; i < NI * 32; i += NT) {
             const int ni = i >> 5, l = i & 31;
             double t1 = 0.0, t2 = 0.0;
-            for (int w = 0; w < WAVES; ++w) {
+            for (int w = 0; w < WAVES * KSP; ++w) {
                 t1 += red[((w * NI + ni) * 32 + l) * 2 + 0];
                 t2 += red[((w * NI + ni) * 32 + l) * 2 + 1];
             }
@@ -518,6 +536,11 @@ static int chunk_ck(const ccdm_conv_args& a, const ConvGeo& g) {
     const bool ok32 = g.TW < 32 && a.stride == 1 && C % 32 == 0 && (a.C1 == 0 || a.C0 % 32 == 0) &&
                       (!a.skip0 || (SC % 32 == 0 && (a.SC1 == 0 || a.SC0 % 32 == 0)));
     return ok32 ? 32 : 16;
+}
+
+static bool tap_split(const ccdm_conv_args& a, const ConvGeo& g) {
+    // measured: pays at 8x8 images (27 -> 18 us for 128->128), loses at 16x16 (25 -> 33 us with 12-wave blocks)
+    return (a.prec & 255) != CCDM_PREC_F32 && a.ksize == 3 && a.stride == 1 && g.TW == 8 && (a.Cout & 3) == 0;
 }
 
 template <int PREC, int CKT, int KS, int STRIDE, int TH, int TW, int WAVES, int MI>
@@ -542,6 +565,12 @@ static int launch_geo(const ConvK& k, const ConvGeo& g, int NI, int ck, dim3 gri
     constexpr int CK0 = PREC == CCDM_PREC_F32 ? 32 : 16;
     if (k.a.stride == 2) return launch_ni<PREC, CK0, KS, 2, 8, 8, 2, 1>(k, NI, grid, lds, s);
     if (g.TW == 32) return launch_ni<PREC, CK0, KS, 1, 8, 32, 4, 2>(k, NI, grid, lds, s);
+    if (PREC != CCDM_PREC_F32 && KS == 3 && tap_split(k.a, g)) {       // small-spatial 3x3: kernel rows split over 3 wave groups
+        constexpr int KSPL = KS == 3 ? 3 : 1;
+        if (ck == 32) hipLaunchKernelGGL((k_conv<PREC, 32, KS, 1, 8, 8, 2, 1, 1, KSPL>), grid, dim3(2 * KSPL * 64), lds, s, k);
+        else hipLaunchKernelGGL((k_conv<PREC, CK0, KS, 1, 8, 8, 2, 1, 1, KSPL>), grid, dim3(2 * KSPL * 64), lds, s, k);
+        return 0;
+    }
     if (PREC != CCDM_PREC_F32 && ck == 32) {
         if (g.TW == 16) return launch_ni<PREC, 32, KS, 1, 8, 16, 4, 1>(k, NI, grid, lds, s);
         return launch_ni<PREC, 32, KS, 1, 8, 8, 2, 1>(k, NI, grid, lds, s);
@@ -553,7 +582,7 @@ static int launch_geo(const ConvK& k, const ConvGeo& g, int NI, int ck, dim3 gri
 template <int PREC>
 static int launch_prec(const ConvK& k, const ConvGeo& g, int NI, int ck, dim3 grid, size_t lds, hipStream_t s) {
 #ifdef CCDM_EXPERIMENT   // compile one instantiation only (register/ISA experiments)
-    hipLaunchKernelGGL((k_conv<CCDM_PREC_F16X3, CCDM_EXPERIMENT_CK, 3, 1, CCDM_EXPERIMENT_GEO, 1>), grid, dim3(256), lds, s, k);
+    hipLaunchKernelGGL((k_conv<CCDM_PREC_F16X3, CCDM_EXPERIMENT_CK, 3, 1, CCDM_EXPERIMENT_GEO>), grid, dim3(256), lds, s, k);
     return 0;
 #else
     if (k.a.ksize == 3) return launch_geo<PREC, 3>(k, g, NI, ck, grid, lds, s);
@@ -632,9 +661,10 @@ int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
     size_t lds = (size_t)HP * (prec == CCDM_PREC_F32 ? 33 * 4 : ck * 4 + 16);
     lds = (lds + 15) / 16 * 16;
     if (prec != CCDM_PREC_F32) lds += (size_t)a.ksize * a.ksize * (ck / 16) * NI * 128 * 16;     // staged B chunk
-    const size_t red = (size_t)g.waves * NI * 32 * 16;
+    const int ksp = tap_split(a, g) ? 3 : 1;
+    const size_t red = (size_t)g.waves * ksp * NI * 32 * 16;
     if (lds < red) lds = red;
-    const size_t epi = (size_t)g.waves * g.MI * 32 * 36 * 4;        // epilogue transpose buffer (wave-private rows)
+    const size_t epi = (size_t)g.waves * ksp * g.MI * 32 * 36 * 4;        // epilogue transpose buffer (wave-private rows)
     if (lds < epi) lds = epi;
     if (a.stats0) lds += (size_t)C * 8;
     CCDM_REQUIRE(lds <= 160 * 1024, "conv: LDS %zu too large", lds);
