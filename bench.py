@@ -58,13 +58,14 @@ def cpu_baseline(sd, image4, seed=0):
     t0 = time.perf_counter()
     O.forward_denoising(sd, cfg, sched, x, image4, None, 1, "confidence")            # warm-up: 1 step
     warm = time.perf_counter() - t0
-    n_steps = 8 if warm < 2.0 else 2                                                # keep the sample bounded (~10-30 s)
+    # bounded sample: ~15 s of CPU work (first step includes one-time warm-up, so this over-estimates the step time a bit)
+    n_steps = int(max(2, min(T_STEPS, 15.0 / max(warm, 1e-3))))
     t0 = time.perf_counter()
     O.forward_denoising(sd, cfg, sched, x, image4, None, n_steps, "confidence")
     dt = time.perf_counter() - t0
     ms_step = dt / n_steps * 1e3
     return {"value": 4.0 / (ms_step * 1e-3 * T_STEPS), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle (torch-CPU fp32) N=4, {n_steps} of {T_STEPS} denoise steps timed ({dt:.1f} s), extrapolated x{T_STEPS}/{n_steps}",
+            "sample": f"oracle (torch-CPU fp32, {torch.get_num_threads()} threads) N=4, {n_steps} of {T_STEPS} denoise steps timed ({dt:.1f} s), extrapolated x{T_STEPS}/{n_steps}",
             "ms_per_denoise_step_n4": ms_step}
 
 
@@ -165,8 +166,14 @@ def main():
             mean_ms = sum(k[0] * k[1] for k in kern) / cnt
             b = dominant_kernel_bytes(n)
             ach = b["total"] / (mean_ms * 1e-3) / 1e9
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_dominant_kernel.json")
+            if os.path.exists(pmc) and n == PER_GPU_BATCH and args.prec == "f16x3":
+                # HBM bytes per launch of this kernel from the committed rocprofv3 --pmc passes (tools/pmc_conv.sh;
+                # FETCH_SIZE x2 + WRITE_SIZE, KiB, per MI355X_MICROARCH.md) — collected off-line, same shape and batch
+                traffic = json.load(open(pmc)).get("hbm_bytes")
             res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                               "traffic": None, "kernel": f"k_conv<{args.prec},8,32,4,2,1> (" + eng.op_names[dom] + ": conv3x3 32->32 @128x128, GN+SiLU on load)",
+                               "traffic": traffic, "kernel": f"k_conv<{args.prec},8,32,4,2,1> (" + eng.op_names[dom] + ": conv3x3 32->32 @128x128, GN+SiLU on load)",
                                "avg_launch_ms": mean_ms, "launches_timed": cnt, "algorithmic_bytes_per_launch": b["total"],
                                "achieved_conv_io_only": (b["conv_io"] + b["weights"]) / (mean_ms * 1e-3) / 1e9}
         else:
