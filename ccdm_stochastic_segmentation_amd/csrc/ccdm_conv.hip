@@ -44,6 +44,8 @@ template <int PREC, int CKT> struct Lds {
     static constexpr int PIXB = PREC == CCDM_PREC_F32 ? 33 * 4 : CKT * 4 + 16;
 };
 
+static constexpr float ACT_PRESCALE = 16.0f;       // F16X3 activation pre-scale (power of two)
+
 __device__ __forceinline__ float silu_fast(float x) {
     // x * sigmoid(x) with v_exp_f32 / v_rcp_f32 (1 ulp each); limits: x -> -inf gives -0, x -> +inf gives x
     return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
@@ -268,6 +270,12 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                     d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
                 } else {
                     // fp16 hi/lo split: x = hi + lo + O(2^-22 |x|); both halves round-to-nearest
+                    // (saturate at fp16's largest finite value instead of producing inf: |x| up to 1.3e5 then still splits
+                    //  exactly into hi + lo, beyond that the operand clips — raw residual-stream inputs are unbounded in principle)
+                    // Activations are pre-scaled by 2^4 (exact; undone through the weight-scale table) so that the lo half of
+                    // values down to ~2e-3 stays in fp16's normal range; full split precision holds for 2e-3 <= |x| <= 4094.
+                    v.x = __builtin_amdgcn_fmed3f(v.x * ACT_PRESCALE, -65504.f, 65504.f); v.y = __builtin_amdgcn_fmed3f(v.y * ACT_PRESCALE, -65504.f, 65504.f);
+                    v.z = __builtin_amdgcn_fmed3f(v.z * ACT_PRESCALE, -65504.f, 65504.f); v.w = __builtin_amdgcn_fmed3f(v.w * ACT_PRESCALE, -65504.f, 65504.f);
                     f16x4 hi, lo;
                     hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
                     lo[0] = (_Float16)(v.x - (float)hi[0]); lo[1] = (_Float16)(v.y - (float)hi[1]);
@@ -703,7 +711,8 @@ extern "C" int ccdm_conv2d(const ccdm_conv_args* a, void* stream) {
 //                   element j holds W[cout = nt*32 + (l&31)][cin = 16*ks + 8*(l>>5) + j][tap] * 2^e(cout), split
 //                   into fp16 hi + lo (v_mfma_f32_32x32x16_f16), followed by [ntiles*32] floats 2^-e(cout).
 //                   The per-output-channel power of two puts max|W| of the channel in [2^9, 2^10) so hi and lo
-//                   both sit in fp16's normal range; it is exact and undone exactly in the epilogue.
+//                   both sit in fp16's normal range; it is exact and undone exactly in the epilogue (the table also
+//                   carries 2^-4 for the kernel's activation pre-scale).
 extern "C" size_t ccdm_pack_conv_weight_ex(const float* oihw, int Cout, int Cin, int ksize, int prec, const float* cout_absmax, void* out);
 
 extern "C" size_t ccdm_pack_conv_weight(const float* oihw, int Cout, int Cin, int ksize, int prec, void* out) {
@@ -745,7 +754,7 @@ extern "C" size_t ccdm_pack_conv_weight_ex(const float* oihw, int Cout, int Cin,
         if (e > 60) e = 60;
         if (e < -60) e = -60;
         mul[co] = ldexpf(1.0f, e);
-        sc[co] = ldexpf(1.0f, -e);
+        sc[co] = ldexpf(1.0f, -e) / ccdm::ACT_PRESCALE;     // also undoes the kernel's activation pre-scale
     }
     for (int tap = 0; tap < taps; ++tap)
         for (int ks = 0; ks < cin_pad / 16; ++ks)

@@ -516,3 +516,73 @@ def test_checkpoint_file_roundtrip(U, tmp_path, lidc_model):
     a = model(x, image, t=t, validation=True)["diffusion_out"]
     b = m2(x, image, t=t, validation=True)["diffusion_out"]
     assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------ range / other configs
+@pytest.mark.parametrize("scale", [1e-2, 1.0, 3e2, 8e2])
+def test_f16x3_dynamic_range(U, scale):
+    """The split-fp16 path keeps fp32-level relative accuracy over the activation magnitudes a raw (un-normalised)
+    conv input can have: documented full-precision window 2e-3 <= |x| <= 4094 (x16 pre-scale, saturating at fp16 max);
+    GroupNorm'ed inputs are O(1) by construction."""
+    rng = np.random.default_rng(5)
+    x = rnd(rng, 2, 64, 16, 16) * scale
+    w = rnd(rng, 64, 64, 3, 3) / np.sqrt(64 * 9)
+    w[:8] *= 1e-4                     # some output channels with tiny weights: per-channel pre-scale must keep them exact
+    b = torch.zeros(64)
+    ref = F.conv2d(x.double(), w.double(), None, padding=1).float()
+    out, _ = U.conv2d([U.nhwc(x)], w.numpy(), b.numpy(), 3, prec=hip.PREC_F16X3)
+    got = U.bchw(out)
+    assert torch.isfinite(got).all()
+    denom = ref.abs().amax(dim=(0, 2, 3), keepdim=True)             # per output channel
+    rel = ((got - ref).abs() / denom).max().item()
+    print("scale", scale, "max rel err", rel)
+    assert rel < 3e-6
+
+
+def test_c4_shaped_step_vs_oracle(U):
+    """BASELINE config C4 shape (Cityscapes 256x512, K=20, DINO features at stride 8, base 32), N=1, one U-Net step
+    against the oracle: 6-level network, 2048/512/128-token attention, 448-channel widened block."""
+    fce = dict(type="dino", channels=384, output_stride=8, scale="single", target_layer=10)
+    model = build_model(250, "cosine", None, [(3, 256, 512), (20, 256, 512)], (3, 256, 512), "unet_openai", LIDC_BP,
+                        "datasets.cityscapes", "confidence", fce)
+    assert model.unet.spec.num_params() == 7802996                      # SURVEY §8a A9
+    sd = {k: torch.from_numpy(v) for k, v in make_synthetic_state_dict(model.unet.spec, 4).items()}
+    model.unet.load_state_dict(sd, strict=True)
+    model = model.to("cuda:0").eval()
+    model.prec = hip.PREC_F16X3
+    rng = np.random.default_rng(4)
+    img = torch.from_numpy(rng.standard_normal((1, 3, 256, 512)).astype(np.float32))
+    feat = torch.from_numpy(rng.standard_normal((1, 384, 32, 64)).astype(np.float32))
+    idx = torch.from_numpy(rng.integers(0, 20, (1, 256, 512)))
+    x = O.one_hot_bchw(idx, 20)
+    t = torch.full((1,), 77.0)
+    out = model(x.to(U.DEV), img.to(U.DEV), feat.to(U.DEV), t=t, validation=True)["diffusion_out"].cpu()
+    torch.set_num_threads(16)
+    ref = O.unet_forward(sd, dict(LIDC_CFG, feature_condition_idx=[10]), x, img, feat, t)["diffusion_out"]
+    err = (out - ref).abs().max().item()
+    print("C4-shaped step max|dp| =", err)
+    assert err < 1e-4
+    # two strided sampling steps run end to end with the device RNG and stay normalised
+    model.rng, model.philox_seed = "philox", 1
+    y = model(x.to(U.DEV), img.to(U.DEV), feat.to(U.DEV), t=torch.as_tensor(10002))["diffusion_out"]
+    assert torch.isfinite(y).all() and (y.sum(1) - 1).abs().max() < 1e-5
+
+
+def test_c5_shaped_step_properties(U):
+    """BASELINE config C5 shape (Cityscapes 512x1024, K=20, base 64, 7 levels, attention over 8192 tokens), N=1:
+    runs, is normalised, and is bit-reproducible.  (The oracle needs minutes per step at this size.)"""
+    bp = dict(LIDC_BP, base_channels=64)
+    model = build_model(250, "cosine", None, [(3, 512, 1024), (20, 512, 1024)], (3, 512, 1024), "unet_openai", bp,
+                        "datasets.cityscapes", "confidence", None)
+    assert model.unet.spec.num_params() == 29306996                     # SURVEY §8a A9
+    model.unet.load_state_dict({k: torch.from_numpy(v) for k, v in make_synthetic_state_dict(model.unet.spec, 5).items()}, strict=True)
+    model = model.to("cuda:0").eval()
+    model.prec = hip.PREC_F16X3
+    rng = np.random.default_rng(5)
+    img = torch.from_numpy(rng.standard_normal((1, 3, 512, 1024)).astype(np.float32)).to(U.DEV)
+    x = O.one_hot_bchw(torch.from_numpy(rng.integers(0, 20, (1, 512, 1024))), 20).to(U.DEV)
+    t = torch.full((1,), 120.0)
+    a = model(x, img, t=t, validation=True)["diffusion_out"]
+    b = model(x, img, t=t, validation=True)["diffusion_out"]
+    assert torch.isfinite(a).all() and (a.sum(1) - 1).abs().max() < 1e-5 and a.std() > 1e-3
+    assert torch.equal(a, b)
