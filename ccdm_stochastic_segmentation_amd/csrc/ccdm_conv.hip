@@ -23,6 +23,7 @@
 // :242-262; skip 1x1 :221-228; Downsample :137-146; Upsample :106-116; AttentionBlock norm+qkv / proj_out
 // :291-300; stem :517; head GN-SiLU-conv :701-707.   GroupNorm32 = nn.py:17-19,93-100.
 #include "ccdm_common.h"
+#include "ccdm_conv_common.h"
 
 #include <cmath>
 #include <vector>
@@ -44,56 +45,7 @@ template <int PREC, int CKT> struct Lds {
     static constexpr int PIXB = PREC == CCDM_PREC_F32 ? 33 * 4 : CKT * 4 + 16;
 };
 
-static constexpr float ACT_PRESCALE = 16.0f;       // F16X3 activation pre-scale (power of two)
-
-__device__ __forceinline__ float silu_fast(float x) {
-    // x * sigmoid(x) with v_exp_f32 / v_rcp_f32 (1 ulp each); limits: x -> -inf gives -0, x -> +inf gives x
-    return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
-}
-
-struct ConvK {   // kernel-side copy of ccdm_conv_args (+ derived)
-    ccdm_conv_args a;
-    int cin_pad, ntiles, slices, tiles_x, tiles_y;
-    int cin_pad_skip;        // padded channels of the fused 1x1 skip segment (0: none)
-    const float* wscale;     // F16X3: [ntiles*32] powers of two undoing the per-output-channel weight pre-scale
-};
-
-// ---------------------------------------------------------------------------------------------------
-// GroupNorm affine for sample n:  ab[c] = (scale, shift) such that  y = scale*x + shift
-// ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void compute_gn_affine(const ccdm_conv_args& a, int n, int emb_row, float2* ab) {
-    const int C = a.C0 + a.C1;
-    const int cpg = C / 32;
-    const double cnt = (double)cpg * (double)a.Hin * (double)a.Win;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const int c_lo = (c / cpg) * cpg;
-        double sum = 0.0, sq = 0.0;
-        for (int cc = c_lo; cc < c_lo + cpg; ++cc) {
-            const double* st; int ci, Cs, S;
-            if (cc < a.C0) { st = a.stats0; ci = cc; Cs = a.C0; S = a.slices0; }
-            else { st = a.stats1; ci = cc - a.C0; Cs = a.C1; S = a.slices1; }
-            const double* p = st + ((size_t)n * S * Cs + ci) * 2;
-            for (int s = 0; s < S; ++s) {
-                sum += p[(size_t)s * Cs * 2];
-                sq += p[(size_t)s * Cs * 2 + 1];
-            }
-        }
-        const double mean = sum / cnt;
-        double var = sq / cnt - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
-        const float meanf = (float)mean;
-        float sc = rstd * a.gamma[c];
-        float sh = a.beta[c] - sc * meanf;
-        if (a.film) {   // h = GN(h) * (1 + scale) + shift          unet.py:254-258
-            const float* row = a.emb_table + (size_t)emb_row * a.emb_stride + a.film_off;
-            const float one_plus = 1.0f + row[c];
-            sc = sc * one_plus;
-            sh = sh * one_plus + row[C + c];
-        }
-        ab[c] = make_float2(sc, sh);
-    }
-}
+// (ACT_PRESCALE, silu_fast, ConvK, compute_gn_affine: ccdm_conv_common.h)
 
 // register budget: >= 3 waves per SIMD (<= 168 VGPRs) when the accumulator tile is small — matches the 3 blocks
 // per CU the LDS footprint (A tile 27 KB + B chunk 18 KB) admits

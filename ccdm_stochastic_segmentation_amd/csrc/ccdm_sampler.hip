@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void k_posterior(const ccdm_post_args a) {
     const int mode = (int)row[2];
 
     float x0[KP];
-    const float* hp = a.head + i * K;
+    const float* hp = a.head + i * a.head_stride;
 #pragma unroll
     for (int k = 0; k < KP; ++k) x0[k] = k < K ? hp[k] : -INFINITY;
     if (a.softmax) {
@@ -182,6 +182,7 @@ __global__ __launch_bounds__(256) void k_posterior(const ccdm_post_args a) {
 int launch_posterior(const ccdm_post_args& a, hipStream_t s) {
     CCDM_REQUIRE(a.head && a.xt && a.step_table && a.xt_next, "posterior: null pointer");
     CCDM_REQUIRE(a.K >= 2 && a.K <= 32, "posterior: K=%d outside [2,32]", a.K);
+    CCDM_REQUIRE(a.head_stride >= a.K, "posterior: head_stride %d < K %d", a.head_stride, a.K);
     const size_t npix = (size_t)a.N * a.HW;
     if (!npix) return 0;
     dim3 grid((unsigned)((npix + 255) / 256)), block(256);

@@ -263,11 +263,17 @@ class SamplerEngine:
         h = self._layers(spec.middle_block, [h])
         for blk in spec.output_blocks:
             h = self._layers(blk, [h, hs.pop()])
-        self.head = self._conv([h], "out.2", K, 3, gn="out.0", act=hip.ACT_SILU, stats=False)
+        # head conv: K output channels padded to a multiple of 4 (zero weights) so it takes the float4 epilogue
+        Kp = (K + 3) // 4 * 4
+        if Kp != K:
+            wk, bk = self._sd["out.2.weight"], self._sd["out.2.bias"]
+            self._sd["out.2.weight"] = torch.cat([wk, torch.zeros((Kp - K,) + tuple(wk.shape[1:]))], 0)
+            self._sd["out.2.bias"] = torch.cat([bk, torch.zeros(Kp - K)], 0)
+        self.head = self._conv([h], "out.2", Kp, 3, gn="out.0", act=hip.ACT_SILU, stats=False)
         self.n_unet_ops = lib.ccdm_engine_num_ops(self._handle)
 
         post = hip.PostArgs()
-        post.head, post.softmax = self.head.ptr, int(spec.softmax_output)
+        post.head, post.softmax, post.head_stride = self.head.ptr, int(spec.softmax_output), self.head.C
         post.xt, post.N, post.HW, post.K = self.xt.data_ptr(), N, H * W, K
         post.step_table, post.step_ptr = self.step_table.data_ptr(), 0
         post.noise, post.noise_step_stride = 0, 0

@@ -47,7 +47,7 @@ class ConvArgs(C.Structure):
 
 class PostArgs(C.Structure):
     _fields_ = [
-        ("head", C.c_void_p), ("softmax", C.c_int32),
+        ("head", C.c_void_p), ("softmax", C.c_int32), ("head_stride", C.c_int32),
         ("xt", C.c_void_p),
         ("N", C.c_int32), ("HW", C.c_int32), ("K", C.c_int32),
         ("step_table", C.c_void_p), ("step_ptr", C.c_void_p),
@@ -101,7 +101,7 @@ class CcdmHipError(RuntimeError):
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile libccdm_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "ccdm_common.h"), os.path.join(ROOT, "include", "ccdm_hip.h")]
+    deps = srcs + [os.path.join(CSRC, "ccdm_common.h"), os.path.join(CSRC, "ccdm_conv_common.h"), os.path.join(ROOT, "include", "ccdm_hip.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     cmd = ["hipcc", *HIPCC_FLAGS, "-I" + os.path.join(ROOT, "include"), *srcs, "-o", LIB_PATH]

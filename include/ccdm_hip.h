@@ -127,8 +127,9 @@ enum { CCDM_STEP_SAMPLE = 0, CCDM_STEP_LAST_CONFIDENCE = 1, CCDM_STEP_LAST_MAJOR
        CCDM_STEP_SOFTMAX_ONLY = 4 /* out_probs = x0 (the U-Net output itself): forward_step, diffusion_denoising.py:161-162 */ };
 
 typedef struct ccdm_post_args {
-    const float* head;           /* dev [N,HW,K] head conv output (logits, or probabilities if !softmax) */
+    const float* head;           /* dev [N,HW,head_stride] head conv output (logits, or probabilities if !softmax), first K channels used */
     int32_t softmax;             /* 1: apply softmax over K first */
+    int32_t head_stride;         /* floats per pixel of `head` (>= K; the head conv pads K up to a multiple of 4) */
     const uint8_t* xt;           /* dev [N,HW] class index of x_t */
     int32_t N, HW, K;
     /* per-step coefficients: row = *step_ptr (0 if NULL) of step_table = {alpha_t, cumalpha_tm1, mode, 0} */

@@ -128,6 +128,7 @@ def posterior_sample(head_nhwk, xt_idx, a, c, mode, *, softmax=True, noise=None,
     post = torch.zeros((N, HW, K), device=DEV)
     p = hip.PostArgs()
     p.head, p.softmax, p.xt = head_nhwk.data_ptr(), int(softmax), xt_idx.data_ptr()
+    p.head_stride = K
     p.N, p.HW, p.K = N, HW, K
     p.step_table, p.step_ptr = table.data_ptr(), stepbuf.data_ptr()
     if noise is not None:
