@@ -173,7 +173,8 @@ def main():
                 # FETCH_SIZE x2 + WRITE_SIZE, KiB, per MI355X_MICROARCH.md) — collected off-line, same shape and batch
                 traffic = json.load(open(pmc)).get("hbm_bytes")
             res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                               "traffic": traffic, "kernel": f"k_conv<{args.prec},8,32,4,2,1> (" + eng.op_names[dom] + ": conv3x3 32->32 @128x128, GN+SiLU on load)",
+                               "traffic": traffic, "kernel": ("ccdm::k_conv<1, 16, 3, 1, 8, 32, 4, 2, 1, 1>" if args.prec == "f16x3" else "ccdm::k_conv<0, 32, 3, 1, 8, 32, 4, 2, 1, 1>")
+                                         + " = <PREC,CK,KS,STRIDE,TH,TW,WAVES,MI,NI,KSP>, engine op 1 (" + eng.op_names[dom] + ": conv3x3 32->32 @128x128, GN+SiLU on load)",
                                "avg_launch_ms": mean_ms, "launches_timed": cnt, "algorithmic_bytes_per_launch": b["total"],
                                "achieved_conv_io_only": (b["conv_io"] + b["weights"]) / (mean_ms * 1e-3) / 1e9}
         else:

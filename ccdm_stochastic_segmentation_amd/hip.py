@@ -119,6 +119,11 @@ def load() -> C.CDLL:
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):
+        # not built yet: compile it now if a hipcc is around (the GPU box has the same ROCm image); otherwise fail loudly
+        import shutil
+        if shutil.which("hipcc") and os.path.isdir(CSRC) and not os.environ.get("CCDM_NO_AUTOBUILD"):
+            build(force=True)
+    if not os.path.exists(LIB_PATH):
         raise CcdmHipError(
             f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
             "Build it with `python -c 'import __graft_entry__ as g; g.build()'`.")

@@ -81,6 +81,7 @@ def test_pack_conv_weight_layout():
 def test_missing_library_is_a_hard_error(monkeypatch, tmp_path):
     monkeypatch.setattr(hip, "_lib", None)
     monkeypatch.setattr(hip, "LIB_PATH", str(tmp_path / "nope.so"))
+    monkeypatch.setenv("CCDM_NO_AUTOBUILD", "1")
     with pytest.raises(hip.CcdmHipError, match="no CPU fallback"):
         hip.load()
 
