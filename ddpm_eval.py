@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
-"""Entry point with the reference's name, arguments and dispatch (/root/reference/ddpm_eval.py:28-47):
+"""Evaluation entry point, same command line as the reference's script of this name (/root/reference/ddpm_eval.py:28-47):
 
-    python ddpm_eval.py [params_eval.yml]
+    python ddpm_eval.py [params_<anything>.yml]
 
-runs the LIDC uncertainty evaluation (or the sampling-speed sweep when dataset_file contains
-'lidc_sampling_speed') through the MI355X sampler."""
+`dataset_file` in the YAML selects the evaluator: "...lidc_sampling_speed" -> the T-sweep timing run,
+"...lidc" -> GED / HM-IoU over the LIDC test split.  Everything runs through the MI355X sampler; the result
+dictionary is also printed as one JSON line so scripts can pick it up."""
 import json
 import logging
 import os
@@ -15,36 +16,48 @@ import numpy as np
 import torch
 import yaml
 
-from ccdm_stochastic_segmentation_amd.evaluation import eval_lidc_sampling_speed, eval_lidc_uncertainty
+from ccdm_stochastic_segmentation_amd import evaluation
+
+DEFAULT_PARAMS = "params_eval.yml"
+SEED = 0
 
 
-def set_seeds(seed: int):
-    random.seed(seed)
+def _seed_everything(seed):
+    # the reference seeds python, numpy and torch (cpu + every gpu) with 0 before anything else runs
     os.environ["PYTHONHASHSEED"] = str(seed)
-    np.random.seed(seed % 2 ** 32)
-    torch.manual_seed(seed)
-    torch.cuda.manual_seed_all(seed)
+    for seeder in (random.seed, lambda s: np.random.seed(s % 2 ** 32), torch.manual_seed, torch.cuda.manual_seed_all):
+        seeder(seed)
+
+
+def _params_path(argv):
+    # only an argument that looks like a params file overrides the default, as in the reference
+    if len(argv) == 2 and "params_" in argv[1]:
+        print(f"Overriding params file with {argv[1]}...")
+        return argv[1]
+    return DEFAULT_PARAMS
+
+
+def _pick_evaluator(dataset_file):
+    """-> (evaluator, dataset_file to hand it).  Order matters: the speed sweep's name contains 'lidc'."""
+    if "lidc_sampling_speed" in dataset_file:
+        return evaluation.eval_lidc_sampling_speed, dataset_file.replace("lidc_sampling_speed", "lidc")
+    if "lidc" in dataset_file:
+        return evaluation.eval_lidc_uncertainty, dataset_file
+    if "cityscapes" in dataset_file:
+        raise NotImplementedError("the Cityscapes evaluator is broken on the reference's main branch "
+                                  "(SURVEY §2 #22) and is out of scope")
+    raise ValueError("Unknown dataset")
 
 
 def main(argv):
     logging.basicConfig(level=logging.INFO, format="%(asctime)s [%(name)s] %(message)s")
-    set_seeds(0)
-    params_file = "params_eval.yml"
-    if len(argv) == 2 and "params_" in argv[1]:
-        params_file = argv[1]
-        print(f"Overriding params file with {params_file}...")
-    with open(params_file, "r") as f:
-        params = yaml.safe_load(f)
-    if "lidc_sampling_speed" in params["dataset_file"]:
-        params["dataset_file"] = params["dataset_file"].replace("lidc_sampling_speed", "lidc")
-        res = eval_lidc_sampling_speed(params, synthetic_weights_seed=0 if "synthetic" in params["dataset_file"] else None)
-    elif "lidc" in params["dataset_file"]:
-        res = eval_lidc_uncertainty(params, synthetic_weights_seed=0 if "synthetic" in params["dataset_file"] else None)
-    elif "cityscapes" in params["dataset_file"]:
-        raise NotImplementedError("the Cityscapes evaluator is broken on the reference's main branch (SURVEY §2 #22) and is out of scope")
-    else:
-        raise ValueError("Unknown dataset")
-    print(json.dumps(res))
+    _seed_everything(SEED)
+    with open(_params_path(argv)) as fh:
+        params = yaml.safe_load(fh)
+    evaluator, params["dataset_file"] = _pick_evaluator(params["dataset_file"])
+    synthetic = "synthetic" in params["dataset_file"]
+    result = evaluator(params, synthetic_weights_seed=SEED if synthetic else None)
+    print(json.dumps(result))
 
 
 if __name__ == "__main__":

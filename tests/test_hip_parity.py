@@ -586,3 +586,30 @@ def test_c5_shaped_step_properties(U):
     b = model(x, img, t=t, validation=True)["diffusion_out"]
     assert torch.isfinite(a).all() and (a.sum(1) - 1).abs().max() < 1e-5 and a.std() > 1e-3
     assert torch.equal(a, b)
+
+
+def test_c3_shaped_t1000_sharded_sampling(U):
+    """BASELINE config C3 shape: T=1000, S samples per image, batch sharded by `sample_sharded` (single process here:
+    the multi-rank path is the gloo test).  Strided 5-step walk from t=1000; the shard slices reproduce the full batch."""
+    from ccdm_stochastic_segmentation_amd.distributed import sample_sharded, shard_range
+    model = build_model(1000, "cosine", {"s": 0.008}, [(1, 128, 128), (2, 128, 128)], (1, 128, 128), "unet_openai", LIDC_BP,
+                        "datasets.lidc", "majority", None)
+    model.unet.load_state_dict({k: torch.from_numpy(v) for k, v in make_synthetic_state_dict(model.unet.spec, 0).items()}, strict=True)
+    model = model.to("cuda:0").eval()
+    assert model.time_steps == 1000
+    model.prec, model.rng, model.philox_seed = hip.PREC_F16X3, "philox", 7
+    rng = np.random.default_rng(9)
+    B_img, S = 2, 4
+    image = torch.from_numpy(rng.uniform(-1, 1, (B_img, 1, 128, 128)).astype(np.float32)).to(U.DEV).repeat_interleave(S, dim=0)
+    x = O.one_hot_bchw(torch.from_numpy(rng.integers(0, 2, (B_img * S, 128, 128))), 2).to(U.DEV)
+    t = torch.as_tensor(10005)
+    full = sample_sharded(model, x, image, t=t)
+    assert full.dtype == torch.int64 and full.shape == (B_img * S, 2, 128, 128) and (full.sum(1) == 1).all()
+    # what rank 1 of 3 would compute for its shard (Philox keyed by global sample index)
+    lo, hi = shard_range(B_img * S, 1, 3)
+    model.sample_offset, model.noise_slice = lo, (B_img * S, lo)
+    part = model(x[lo:hi], image[lo:hi], t=t)["diffusion_out"]
+    model.sample_offset, model.noise_slice = 0, None
+    assert torch.equal(part, full[lo:hi])
+    pred = full.reshape(B_img, S, 2, 128, 128)          # [B_img, S, K, H, W] as evaluate_lidc_uncertainty.py:103
+    assert pred.shape[1] == S
