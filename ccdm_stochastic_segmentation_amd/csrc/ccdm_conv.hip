@@ -26,6 +26,7 @@
 #include "ccdm_conv_common.h"
 
 #include <cmath>
+#include <type_traits>
 #include <vector>
 
 namespace ccdm {
@@ -68,13 +69,32 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
     constexpr int PAD = KS / 2;
     constexpr int HHt = (TH - 1) * STRIDE + KS, HWt = (TW - 1) * STRIDE + KS, HP = HHt * HWt;
     constexpr int QPP = CK / 4;                                   // float4 items per halo pixel
-    constexpr int NITEM = (HP * QPP + NT - 1) / NT;               // staging items per thread
-    static_assert(NITEM <= 32, "validity mask is 32 bits");
     static_assert(NT % QPP == 0, "channel quad must be item-invariant");
+    // Stride-1 staging is row-structured: a pass of the block covers RPP whole rows of the TW core columns of the halo
+    // (thread -> (row in pass, column, channel quad), all item-invariant), the 2*PAD edge columns are one extra item for
+    // the first few threads.  Row index and row validity are wave-uniform (scalar ALU), the column part of the address
+    // is computed once per tile-chunk, every LDS address is thread-constant + immediate: staging costs no per-item VALU
+    // beyond the arithmetic on the data itself.  (Stride 2 keeps the generic item -> (hy, hx) walk.)
+    constexpr bool ROWS = STRIDE == 1;
+    constexpr int PXW = NT / QPP;                                 // halo pixels per pass
+    static_assert(!ROWS || PXW % TW == 0, "a pass must cover whole core rows");
+    constexpr int RPP = ROWS ? PXW / TW : 1;                      // core rows per pass
+    constexpr int NCORE = ROWS ? (HHt + RPP - 1) / RPP : 0;
+    constexpr int ECOLS = PAD > 0 ? 2 * PAD : 1;                  // edge columns (1: placeholder when there are none)
+    constexpr int EDGE_ITEMS = ROWS ? HHt * 2 * PAD * QPP : 0;
+    constexpr int NEDGE = (EDGE_ITEMS + NT - 1) / NT;
+    constexpr bool ROW_UNIFORM = ROWS && (TW * QPP) % 64 == 0;    // a wave never straddles two core rows
+    constexpr int NITEM = ROWS ? NCORE + NEDGE : (HP * QPP + NT - 1) / NT;   // staging items per thread
+    static_assert(NITEM <= 32, "validity mask is 32 bits");
     constexpr int A_BYTES = (HP * PIXB + 15) / 16 * 16;
-    // F16X3: the chunk's B fragments, [tap][ni][hi|lo][64 lanes] x 16 B, staged through registers like the halo
-    constexpr int NB4 = PREC == CCDM_PREC_F32 ? 0 : KS * KS * KST * NI * 128;
+    // F16X3: the chunk's B fragments, [tap][k-step] slabs of G = [ni][hi|lo][64 lanes] x 16 B, staged through registers
+    // like the halo.  A pass covers MB whole slabs (or 1/DB of one); the slab index is wave-uniform.
+    constexpr int G = NI * 128;
+    constexpr int NB4 = PREC == CCDM_PREC_F32 ? 0 : KS * KS * KST * G;
     constexpr int NITEM_B = (NB4 + NT - 1) / NT;
+    constexpr bool B_MULTI = NT % G == 0;
+    static_assert(PREC == CCDM_PREC_F32 || B_MULTI || G % NT == 0, "B slabs must tile the block");
+    constexpr int MB = B_MULTI ? NT / G : 1, DB = B_MULTI ? 1 : G / NT;
 
     const ccdm_conv_args& a = k.a;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -133,7 +153,17 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
 
     f32x4 reg[NITEM];
     f32x4 regB[NITEM_B > 0 ? NITEM_B : 1];
-    unsigned valid = 0;
+    unsigned valid = 0;            // generic walk: bit i = item i lies inside the image
+    unsigned rowmask = 0;          // row-structured: bit i = core row of pass i inside the image (wave-uniform)
+    unsigned evalid = 0;           //                 bit j = edge item j inside the image
+    bool xok = false;              //                 this thread's core column (and channel quad) exists
+
+    // thread -> staging coordinates (row-structured walk): channel quad tq, core column px, row within a pass rip.
+    // tq and px are re-derived from an opaque copy of tid inside issue/commit: kept live across the MFMA phase and the
+    // epilogue they cost registers the kernel does not have (3 waves per SIMD = 168), re-deriving them is 3 VALU ops.
+    const int rip = ROW_UNIFORM ? __builtin_amdgcn_readfirstlane((tid / QPP) / TW) : (tid / QPP) / TW;
+    // B staging: slab within a pass (wave-uniform: G >= 128 lanes), item within the slab
+    const unsigned tgB = B_MULTI ? (unsigned)__builtin_amdgcn_readfirstlane(tid / G) : 0u;
 
     // ---- issue: global -> registers for iteration `it` (tile, chunk) ----
     auto issue = [&](int it) {
@@ -146,105 +176,179 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
         const bool second = sC1 > 0 && c0 >= sC0;                 // uniform
         const int Cs = second ? sC1 : sC0, cb = second ? c0 - sC0 : c0;
         const float* srcsel = sk ? (second ? a.skip1 : a.skip0) : (second ? a.in1 : a.in0);
-        const float* srcb = srcsel + (size_t)n * (sk ? out_px : in_px) * Cs;      // uniform per-sample base
+        const char* srcb = reinterpret_cast<const char*>(srcsel + (size_t)n * (sk ? out_px : in_px) * Cs);   // uniform per-sample base
         const int oy0 = (tile / k.tiles_x) * TH, ox0 = (tile % k.tiles_x) * TW;
-        valid = 0;
+        // Every load is issued unconditionally with its address clamped into the tensor; padding is zeroed at commit.
+        // (A conditional load would put a control-flow join between the prefetch and the MFMA phase, and the waitcnt
+        //  pass then drains the whole prefetch (vmcnt(0)) at the join.)
         unsigned t_ = tid;
         asm volatile("" : "+v"(t_));     // recompute the item geometry each call: hoisting it costs more registers than ALU
-        // item = tid + i*NT  ->  halo pixel hp = item / QPP (hy = hp / HWt, hx = hp % HWt), channel quad q = item % QPP.
-        // NT % QPP == 0, so q is the same for every i and hp advances by NT/QPP: (hy, hx) are carried incrementally
-        // (unsigned, no per-item division).
-        constexpr unsigned DHP = NT / QPP, DHY = DHP / HWt, DHX = DHP % HWt;
-        const unsigned q = t_ % QPP, hp0 = t_ / QPP;
-        unsigned hy = hp0 / HWt, hx = hp0 % HWt;
-        const unsigned c = (unsigned)cb + 4u * q;
-        const unsigned cq = min(c, (unsigned)Cs - 4u);
-        const bool cok = c < (unsigned)Cs;
+        if constexpr (ROWS) {
+            const int tq = t_ % QPP, px = (t_ / QPP) % TW;
+            const unsigned c = (unsigned)cb + 4u * (unsigned)tq;
+            const unsigned cq = min(c, (unsigned)Cs - 4u);
+            const bool cok = c < (unsigned)Cs;
+            const unsigned rowb = (unsigned)aWin * (unsigned)Cs * 4u;            // bytes per source row (uniform)
+            {
+                const int ix = ox0 + px;                                           // core columns: halo x = px + PAD
+                xok = cok & (ix < Wc);
+                const int ixc = min(ix, Wc - 1);
+                const unsigned colb = ((unsigned)(a.up ? ixc >> 1 : ixc) * (unsigned)Cs + cq) << 2;
+                rowmask = 0;
 #pragma unroll
-        for (int i = 0; i < NITEM; ++i) {
-            const int iy = oy0 * STRIDE - PAD + (int)hy, ix = ox0 * STRIDE - PAD + (int)hx;
-            // padding test: unsigned compare folds the < 0 and >= extent checks; no short-circuit branches
-            const bool ok = cok & ((unsigned)iy < (unsigned)Hc) & ((unsigned)ix < (unsigned)Wc) & (hy < (unsigned)HHt);
-            // branch-free: the load is always issued (address clamped into the tensor), padding is zeroed at commit.
-            // A conditional load would put a control-flow join between the prefetch and the MFMA phase, and the
-            // waitcnt pass then drains the whole prefetch (vmcnt(0)) at the join.
-            const int iyc = min(max(iy, 0), Hc - 1), ixc = min(max(ix, 0), Wc - 1);
-            const int sy = a.up ? (iyc >> 1) : iyc, sx = a.up ? (ixc >> 1) : ixc;
-            const unsigned off = ((unsigned)(sy * aWin + sx) * (unsigned)Cs + cq) << 2;      // bytes within the sample
-            reg[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(srcb) + off);
-            valid |= (ok ? 1u : 0u) << i;
-            hy += DHY; hx += DHX;
-            if (hx >= (unsigned)HWt) { hx -= HWt; hy += 1; }
-        }
-        if (PREC != CCDM_PREC_F32) {
-            // B chunk: [tap][k-step][ni][hi|lo][lane]; skip chunks carry one tap (1x1): only the first KST*NI*128 items
-            // are meaningful there, the rest re-read the last one
-            const f32x4* wq = reinterpret_cast<const f32x4*>(sk ? a.skip_w : a.w) + ((size_t)(c0 >> 4) * k.ntiles + nt0) * 128;
-            const unsigned wtap = (unsigned)((sk ? k.cin_pad_skip : k.cin_pad) >> 4) * k.ntiles * 128;
-            const unsigned wks = (unsigned)k.ntiles * 128;
-            const int nb4 = sk ? KST * NI * 128 : NB4;
+                for (int i = 0; i < NCORE; ++i) {
+                    const int row = rip + i * RPP;
+                    const int iy = oy0 - PAD + row;
+                    const bool rok = ((unsigned)iy < (unsigned)Hc) & ((i + 1) * RPP <= HHt || row < HHt);
+                    const int iyc = min(max(iy, 0), Hc - 1);
+                    const unsigned sy = (unsigned)(a.up ? iyc >> 1 : iyc);
+                    if constexpr (ROW_UNIFORM) reg[i] = load16_uniform_base(srcb + (size_t)(sy * rowb), colb);
+                    else reg[i] = *reinterpret_cast<const f32x4*>(srcb + (sy * rowb + colb));
+                    rowmask |= (rok ? 1u : 0u) << i;
+                }
+            }
+            evalid = 0;
 #pragma unroll
-            for (int i = 0; i < NITEM_B; ++i) {
-                int j = (int)t_ + i * NT;
-                j = j < nb4 ? j : nb4 - 1;            // unconditional load (keeps regB[] in registers)
-                const unsigned ts = (unsigned)j / (NI * 128), rem = (unsigned)j % (NI * 128);
-                regB[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(wq) +
-                                                          (((ts / KST) * wtap + (ts % KST) * wks + rem) << 4));
+            for (int j = 0; j < NEDGE; ++j) {
+                const unsigned e = t_ + j * NT;
+                const unsigned side = (e / QPP) % ECOLS, row = e / (ECOLS * QPP);
+                const int hx = side < (unsigned)PAD ? (int)side : TW + (int)side;
+                const int iy = oy0 - PAD + (int)row, ix = ox0 - PAD + hx;
+                const bool ok = cok & (e < (unsigned)EDGE_ITEMS) & ((unsigned)iy < (unsigned)Hc) & ((unsigned)ix < (unsigned)Wc);
+                const int iyc = min(max(iy, 0), Hc - 1), ixc = min(max(ix, 0), Wc - 1);
+                const unsigned sy = (unsigned)(a.up ? iyc >> 1 : iyc), sx = (unsigned)(a.up ? ixc >> 1 : ixc);
+                reg[NCORE + j] = *reinterpret_cast<const f32x4*>(srcb + (size_t)(sy * rowb + ((sx * (unsigned)Cs + cq) << 2)));
+                evalid |= (ok ? 1u : 0u) << j;
+            }
+        } else {
+            valid = 0;
+            // item = tid + i*NT  ->  halo pixel hp = item / QPP (hy = hp / HWt, hx = hp % HWt), channel quad q = item % QPP.
+            // NT % QPP == 0, so q is the same for every i and hp advances by NT/QPP: (hy, hx) are carried incrementally
+            // (unsigned, no per-item division).
+            constexpr unsigned DHP = NT / QPP, DHY = DHP / HWt, DHX = DHP % HWt;
+            const unsigned q = t_ % QPP, hp0 = t_ / QPP;
+            unsigned hy = hp0 / HWt, hx = hp0 % HWt;
+            const unsigned c = (unsigned)cb + 4u * q;
+            const unsigned cq = min(c, (unsigned)Cs - 4u);
+            const bool cok = c < (unsigned)Cs;
+#pragma unroll
+            for (int i = 0; i < NITEM; ++i) {
+                const int iy = oy0 * STRIDE - PAD + (int)hy, ix = ox0 * STRIDE - PAD + (int)hx;
+                // padding test: unsigned compare folds the < 0 and >= extent checks; no short-circuit branches
+                const bool ok = cok & ((unsigned)iy < (unsigned)Hc) & ((unsigned)ix < (unsigned)Wc) & (hy < (unsigned)HHt);
+                const int iyc = min(max(iy, 0), Hc - 1), ixc = min(max(ix, 0), Wc - 1);
+                const int sy = a.up ? (iyc >> 1) : iyc, sx = a.up ? (ixc >> 1) : ixc;
+                const unsigned off = ((unsigned)(sy * aWin + sx) * (unsigned)Cs + cq) << 2;      // bytes within the sample
+                reg[i] = *reinterpret_cast<const f32x4*>(srcb + off);
+                valid |= (ok ? 1u : 0u) << i;
+                hy += DHY; hx += DHX;
+                if (hx >= (unsigned)HWt) { hx -= HWt; hy += 1; }
             }
         }
     };
-    // ---- commit: registers -> affine -> SiLU -> LDS (zero where padded) ----
-    auto commit = [&](int it) {
+    // ---- issueB: this chunk's weight fragments, global (L2-resident) -> registers.  Requested at the top of the
+    //      iteration that consumes them — their (short) latency hides behind the commit's arithmetic — so that they
+    //      do not occupy 4*NITEM_B registers across the MFMA phase and the epilogue like the halo prefetch does.
+    auto issueB = [&](int it) {
         const int ch = it % nchunk;
         const bool sk = ch >= nchunk_main;
         const int c0 = (sk ? ch - nchunk_main : ch) * CK;
         unsigned t_ = tid;
         asm volatile("" : "+v"(t_));
-        const unsigned q = t_ % QPP;
+        if (PREC != CCDM_PREC_F32) {
+            // B chunk: [tap][k-step] slabs; skip chunks carry one tap (1x1): only their first KST slabs are meaningful,
+            // the passes beyond re-read slab 0 (the load stays unconditional: regB[] stays in registers)
+            const char* wq = reinterpret_cast<const char*>(sk ? a.skip_w : a.w) + (((size_t)(c0 >> 4) * k.ntiles + nt0) * 128 << 4);
+            const unsigned wtap = (unsigned)((sk ? k.cin_pad_skip : k.cin_pad) >> 4) * k.ntiles * 128;
+            const unsigned wks = (unsigned)k.ntiles * 128;
+            const unsigned nslab = sk ? KST : KS * KS * KST;
+            const unsigned remb = (B_MULTI ? t_ % G : t_) << 4;      // lane offset, 32-bit (hoisted as a 64-bit pair it defeats the saddr form)
 #pragma unroll
-        for (int i = 0; i < NITEM; ++i) {
-            const unsigned item = t_ + i * NT;
-            if (item < (unsigned)(HP * QPP)) {
-                const unsigned hp = item / QPP;
-                float4 v = make_float4(reg[i][0], reg[i][1], reg[i][2], reg[i][3]);
-                if (!((valid >> i) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                else {
-                    if (has_gn && !sk) {
-                        const int c = c0 + 4 * q;
-                        const float2 t0 = ab[c], t1 = ab[c + 1], t2 = ab[c + 2], t3 = ab[c + 3];
-                        v.x = fmaf(v.x, t0.x, t0.y); v.y = fmaf(v.y, t1.x, t1.y);
-                        v.z = fmaf(v.z, t2.x, t2.y); v.w = fmaf(v.w, t3.x, t3.y);
-                    }
-                    if (a.act == CCDM_ACT_SILU && !sk) { v.x = silu_fast(v.x); v.y = silu_fast(v.y); v.z = silu_fast(v.z); v.w = silu_fast(v.w); }
+            for (int i = 0; i < NITEM_B; ++i) {
+                unsigned ts = B_MULTI ? i * MB + tgB : (unsigned)(i / DB);          // wave-uniform
+                const unsigned rem = B_MULTI ? remb : remb + (unsigned)(NT * (i % DB) * 16);
+                ts = ts < nslab ? ts : 0u;
+                const unsigned slab = (ts / KST) * wtap + (ts % KST) * wks;
+                regB[i] = load16_uniform_base(wq + ((size_t)slab << 4), rem);
+            }
+        }
+    };
+    // ---- commit: registers -> affine -> SiLU -> [fp16 hi|lo split] -> LDS (zero where padded) ----
+    // The chunk's transform is uniform (GroupNorm / SiLU apply to the main segment only): one specialised, branch-free
+    // body per combination; padding is a select, not a branch.
+    auto commit_body = [&](auto GN_, auto ACT_, int c0) {
+        constexpr bool GN = decltype(GN_)::value, ACT = decltype(ACT_)::value;
+        unsigned t_ = tid;
+        asm volatile("" : "+v"(t_));
+        const int tq = t_ % QPP, px = (t_ / QPP) % TW;
+        float2 t0 = make_float2(1.f, 0.f), t1 = t0, t2 = t0, t3 = t0;
+        if (GN) { const int c = c0 + 4 * tq; t0 = ab[c]; t1 = ab[c + 1]; t2 = ab[c + 2]; t3 = ab[c + 3]; }
+        auto put = [&](const f32x4 r, const bool ok, const int hp) {
+            float4 v = make_float4(r[0], r[1], r[2], r[3]);
+            if (GN) { v.x = fmaf(v.x, t0.x, t0.y); v.y = fmaf(v.y, t1.x, t1.y); v.z = fmaf(v.z, t2.x, t2.y); v.w = fmaf(v.w, t3.x, t3.y); }
+            if (ACT) { v.x = silu_fast(v.x); v.y = silu_fast(v.y); v.z = silu_fast(v.z); v.w = silu_fast(v.w); }
+            if (PREC == CCDM_PREC_F32) {
+                float* d = halo + hp * 33 + 4 * tq;
+                d[0] = ok ? v.x : 0.f; d[1] = ok ? v.y : 0.f; d[2] = ok ? v.z : 0.f; d[3] = ok ? v.w : 0.f;
+            } else {
+                // fp16 hi/lo split: x = hi + lo + O(2^-22 |x|); both halves round-to-nearest
+                // (saturate at fp16's largest finite value instead of producing inf: |x| up to 1.3e5 then still splits
+                //  exactly into hi + lo, beyond that the operand clips — raw residual-stream inputs are unbounded in principle)
+                // Activations are pre-scaled by 2^4 (exact; undone through the weight-scale table) so that the lo half of
+                // values down to ~2e-3 stays in fp16's normal range; full split precision holds for 2e-3 <= |x| <= 4094.
+                v.x = __builtin_amdgcn_fmed3f(v.x * ACT_PRESCALE, -65504.f, 65504.f); v.y = __builtin_amdgcn_fmed3f(v.y * ACT_PRESCALE, -65504.f, 65504.f);
+                v.z = __builtin_amdgcn_fmed3f(v.z * ACT_PRESCALE, -65504.f, 65504.f); v.w = __builtin_amdgcn_fmed3f(v.w * ACT_PRESCALE, -65504.f, 65504.f);
+                f16x4 hi, lo;
+                hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
+                lo[0] = (_Float16)(v.x - (float)hi[0]); lo[1] = (_Float16)(v.y - (float)hi[1]);
+                lo[2] = (_Float16)(v.z - (float)hi[2]); lo[3] = (_Float16)(v.w - (float)hi[3]);
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                u32x2 hb = __builtin_bit_cast(u32x2, hi), lb = __builtin_bit_cast(u32x2, lo);
+                hb[0] = ok ? hb[0] : 0u; hb[1] = ok ? hb[1] : 0u; lb[0] = ok ? lb[0] : 0u; lb[1] = ok ? lb[1] : 0u;
+                char* d = halo_b + hp * PIXB + 8 * tq;
+                *reinterpret_cast<u32x2*>(d) = hb;
+                *reinterpret_cast<u32x2*>(d + 2 * CK) = lb;
+            }
+        };
+        if constexpr (ROWS) {
+            const int hp0 = rip * HWt + PAD + px;
+#pragma unroll
+            for (int i = 0; i < NCORE; ++i)
+                if ((i + 1) * RPP <= HHt || rip + i * RPP < HHt)
+                    put(reg[i], xok & (((rowmask >> i) & 1u) != 0u), hp0 + i * RPP * HWt);
+#pragma unroll
+            for (int j = 0; j < NEDGE; ++j) {
+                const unsigned e = t_ + j * NT;
+                if (e < (unsigned)EDGE_ITEMS) {
+                    const unsigned side = (e / QPP) % ECOLS, row = e / (ECOLS * QPP);
+                    const int hx = side < (unsigned)PAD ? (int)side : TW + (int)side;
+                    put(reg[NCORE + j], ((evalid >> j) & 1u) != 0u, (int)row * HWt + hx);
                 }
-                if (PREC == CCDM_PREC_F32) {
-                    float* d = halo + hp * 33 + 4 * q;
-                    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-                } else {
-                    // fp16 hi/lo split: x = hi + lo + O(2^-22 |x|); both halves round-to-nearest
-                    // (saturate at fp16's largest finite value instead of producing inf: |x| up to 1.3e5 then still splits
-                    //  exactly into hi + lo, beyond that the operand clips — raw residual-stream inputs are unbounded in principle)
-                    // Activations are pre-scaled by 2^4 (exact; undone through the weight-scale table) so that the lo half of
-                    // values down to ~2e-3 stays in fp16's normal range; full split precision holds for 2e-3 <= |x| <= 4094.
-                    v.x = __builtin_amdgcn_fmed3f(v.x * ACT_PRESCALE, -65504.f, 65504.f); v.y = __builtin_amdgcn_fmed3f(v.y * ACT_PRESCALE, -65504.f, 65504.f);
-                    v.z = __builtin_amdgcn_fmed3f(v.z * ACT_PRESCALE, -65504.f, 65504.f); v.w = __builtin_amdgcn_fmed3f(v.w * ACT_PRESCALE, -65504.f, 65504.f);
-                    f16x4 hi, lo;
-                    hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
-                    lo[0] = (_Float16)(v.x - (float)hi[0]); lo[1] = (_Float16)(v.y - (float)hi[1]);
-                    lo[2] = (_Float16)(v.z - (float)hi[2]); lo[3] = (_Float16)(v.w - (float)hi[3]);
-                    char* d = halo_b + hp * PIXB + 8 * q;
-                    *reinterpret_cast<f16x4*>(d) = hi;
-                    *reinterpret_cast<f16x4*>(d + 2 * CK) = lo;
-                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NITEM; ++i) {
+                const unsigned item = t_ + i * NT;
+                if (item < (unsigned)(HP * QPP)) put(reg[i], ((valid >> i) & 1u) != 0u, (int)(item / QPP));
             }
         }
         if (PREC != CCDM_PREC_F32) {
 #pragma unroll
             for (int i = 0; i < NITEM_B; ++i) {
                 const int j = (int)t_ + i * NT;
-                if (j < NB4) ldsB[j] = regB[i];
+                if ((i + 1) * NT <= NB4 || j < NB4) ldsB[j] = regB[i];
             }
         }
+    };
+    auto commit = [&](int it) {
+        const int ch = it % nchunk;
+        const bool sk = ch >= nchunk_main;
+        const int c0 = (sk ? ch - nchunk_main : ch) * CK;
+        const bool gn = has_gn && !sk, act = a.act == CCDM_ACT_SILU && !sk;
+        if (gn && act) commit_body(std::true_type{}, std::true_type{}, c0);
+        else if (gn) commit_body(std::true_type{}, std::false_type{}, c0);
+        else if (act) commit_body(std::false_type{}, std::true_type{}, c0);
+        else commit_body(std::false_type{}, std::false_type{}, c0);
     };
 
     f32x16 acc[MI][NI];
@@ -262,6 +366,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                     for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
         }
         CCDM_STAMP(2);
+        if (!(dbg & 4)) issueB(it);
         __syncthreads();          // previous MFMA phase has finished reading LDS (and ab[] is visible)
         CCDM_STAMP(3);
         if (!(dbg & 2)) commit(it);
@@ -298,15 +403,12 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                 }
             }
         } else {
-            // taps x {lo*hi, hi*lo, hi*hi} of v_mfma_f32_32x32x16_f16 (one 16-channel k-step per chunk);
-            // A: halo tile, B: [tap][ni][hi|lo][lane] fragments, both in LDS
+            // taps x {lo*hi, hi*lo, hi*hi} of v_mfma_f32_32x32x16_f16 (KST 16-channel k-steps per chunk);
+            // A: halo tile, B: [tap][k-step][ni][hi|lo][lane] fragments, both in LDS.  The tap walk is straight-line code
+            // (the skip segment's single centre tap is its own copy), so the LDS reads of the next tap are scheduled
+            // under the MFMAs of the current one.
             const f16x8* bq = reinterpret_cast<const f16x8*>(ldsB) + lane;
-#pragma unroll
-            for (int tap = 0; tap < KS * KS; ++tap) {
-                if (skc && tap != (KS * KS) / 2) continue;       // skip segment: centre tap only, staged as B slot 0
-                if (KSP > 1 && tap / KS != krow) continue;       // tap split: this wave group owns kernel row `krow`
-                const int bt = skc ? 0 : tap;
-                const int toff = ((tap / KS) * HWt + (tap % KS)) * PIXB;
+            auto tap_mfma = [&](const int toff, const int bt) {
 #pragma unroll
                 for (int ks = 0; ks < KST; ++ks) {
                     f16x8 ah[MI], al[MI];
@@ -328,6 +430,17 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                         for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh, acc[mi][ni], 0, 0, 0);
                     }
                 }
+            };
+            if (skc) {
+                // skip segment: centre tap only, its weights are staged as B slot 0 (tap split: the centre row's group)
+                if (KSP == 1 || krow == KS / 2) tap_mfma((PAD * HWt + PAD) * PIXB, 0);
+            } else if (KSP > 1) {
+                // tap split: this wave group owns kernel row `krow`
+#pragma unroll
+                for (int u = 0; u < KS; ++u) tap_mfma((krow * HWt + u) * PIXB, krow * KS + u);
+            } else {
+#pragma unroll
+                for (int tap = 0; tap < KS * KS; ++tap) tap_mfma(((tap / KS) * HWt + (tap % KS)) * PIXB, tap);
             }
         }
 
@@ -348,18 +461,38 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                     if (KSP > 1 && ni > 0) __syncthreads();        // the partials of the previous n-tile have been consumed
                     const int co4 = (nt0 + ni) * 32 + 4 * cq;
                     const bool cv4 = co4 < a.Cout;
+                    // Row j of this wave's float4 pass is output pixel (oy, ox0 + cx + prow): oy and cx are wave-uniform /
+                    // compile-time (8 | TW), so for a tile that lies fully inside the image and the channel range the
+                    // residual loads and the stores are (scalar row base) + (one thread-constant offset): no per-row VALU.
+                    // Ragged tiles take the checked copy.
+                    const bool full = oy0 + TH <= aHout && ox0 + TW <= aWout && (nt0 + ni) * 32 + 32 <= aCout;   // uniform
+                    constexpr int RS_FIRST = MI * 4 > 4 ? 4 : MI * 4;
                     f32x4 rs[MI * 4];
-                    if (a.resid) {
+                    const unsigned lane_off = ((unsigned)prow * (unsigned)aCout + (unsigned)co4) << 2;
+                    auto row_of = [&](const int j) { return oy0 + wave * (MI * 32 / TW) + (j * 8) / TW; };       // uniform
+                    auto row_base = [&](const int j) {      // byte offset of pixel (oy, ox0 + cx), channel 0, within the sample
+                        return (unsigned)((row_of(j) * aWout + ox0 + (j * 8) % TW) * aCout) << 2;
+                    };
+                    // residual rows: the first half is requested before the transpose (its latency hides behind the LDS
+                    // writes), the second half behind the first half's stores — all of them live at once together with the
+                    // accumulators and the next tile's prefetch would not fit the registers
+                    float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
+                    auto epi_ni = [&](auto FULL_, auto RESID_) {
+                    constexpr bool FULL = decltype(FULL_)::value, RESID = decltype(RESID_)::value;
+                    auto load_resid = [&](const int j0, const int j1) {
 #pragma unroll
-                        for (int j = 0; j < MI * 4; ++j) {
+                        for (int j = j0; j < j1; ++j) {
                             if (KSP > 1 && j % KSP != krow) continue;
-                            const int p = wave * MI * 32 + j * 8 + prow;
-                            const int oy = min(oy0 + p / TW, aHout - 1), ox = min(ox0 + p % TW, aWout - 1);
-                            const int cc = min(co4, aCout - 4);
-                            rs[j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(residn) +
-                                                                    (((unsigned)(oy * aWout + ox) * (unsigned)aCout + (unsigned)cc) << 2));
+                            if (FULL) rs[j] = load16_uniform_base(reinterpret_cast<const char*>(residn) + row_base(j), lane_off);
+                            else {
+                                const int oy = min(row_of(j), aHout - 1), ox = min(ox0 + (j * 8) % TW + prow, aWout - 1);
+                                const int cc = min(co4, aCout - 4);
+                                rs[j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(residn) +
+                                                                        (((unsigned)(oy * aWout + ox) * (unsigned)aCout + (unsigned)cc) << 2));
+                            }
                         }
-                    }
+                    };
+                    if (RESID) load_resid(0, RS_FIRST);
                     {
                         const int co = (nt0 + ni) * 32 + (lane_ & 31);
                         float add = 0.f, wsc = 1.0f;
@@ -380,26 +513,37 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                     }
                     if (KSP > 1) __syncthreads();                  // all row groups' partials are in LDS
                     const float* epi0 = reinterpret_cast<const float*>(halo_b) + wave * (MI * 32 * EPS);   // row group 0 of this sub-tile
-                    float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
+                    {
 #pragma unroll
-                    for (int j = 0; j < MI * 4; ++j) {
-                        if (KSP > 1 && j % KSP != krow) continue;   // the row groups share the final pass
-                        const int pl = j * 8 + prow;
-                        const int p = wave * MI * 32 + pl;
-                        const int oy = oy0 + p / TW, ox = ox0 + p % TW;
-                        f32x4 v = *reinterpret_cast<const f32x4*>(epi0 + pl * EPS + 4 * cq);
+                        for (int j = 0; j < MI * 4; ++j) {
+                            if (j == RS_FIRST && RESID) load_resid(RS_FIRST, MI * 4);   // behind the first half's stores
+                            if (KSP > 1 && j % KSP != krow) continue;   // the row groups share the final pass
+                            const int pl = j * 8 + prow;
+                            f32x4 v = *reinterpret_cast<const f32x4*>(epi0 + pl * EPS + 4 * cq);
 #pragma unroll
-                        for (int g = 1; g < KSP; ++g)               // fixed order: row 0 + row 1 + row 2
-                            v += *reinterpret_cast<const f32x4*>(epi0 + g * (WAVES * MI * 32 * EPS) + pl * EPS + 4 * cq);
-                        if (a.resid) v += rs[j];
-                        if (cv4 && oy < a.Hout && ox < a.Wout) {
-                            if (!(dbg & 8))
-                                *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(outn) +
-                                                          (((unsigned)(oy * aWout + ox) * (unsigned)aCout + (unsigned)co4) << 2)) = v;
+                            for (int g = 1; g < KSP; ++g)               // fixed order: row 0 + row 1 + row 2
+                                v += *reinterpret_cast<const f32x4*>(epi0 + g * (WAVES * MI * 32 * EPS) + pl * EPS + 4 * cq);
+                            if (RESID) v += rs[j];
+                            if (FULL) {
+                                if (!(dbg & 8)) store16_uniform_base(reinterpret_cast<char*>(outn) + row_base(j), lane_off, v);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) { t1[e] += v[e]; t2[e] = fmaf(v[e], v[e], t2[e]); }
+                                for (int e = 0; e < 4; ++e) { t1[e] += v[e]; t2[e] = fmaf(v[e], v[e], t2[e]); }
+                            } else {
+                                const int oy = row_of(j), ox = ox0 + (j * 8) % TW + prow;
+                                if (cv4 && oy < aHout && ox < aWout) {
+                                    if (!(dbg & 8))
+                                        *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(outn) +
+                                                                  (((unsigned)(oy * aWout + ox) * (unsigned)aCout + (unsigned)co4) << 2)) = v;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) { t1[e] += v[e]; t2[e] = fmaf(v[e], v[e], t2[e]); }
+                                }
+                            }
                         }
                     }
+                    };
+                    // one straight-line copy per (full tile, residual) combination: uniform branches taken once
+                    if (a.resid) { if (full) epi_ni(std::true_type{}, std::true_type{}); else epi_ni(std::false_type{}, std::true_type{}); }
+                    else { if (full) epi_ni(std::true_type{}, std::false_type{}); else epi_ni(std::false_type{}, std::false_type{}); }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { s1[ni][e] += t1[e]; s2[ni][e] += t2[e]; }
                 }
@@ -506,16 +650,14 @@ static bool tap_split(const ccdm_conv_args& a, const ConvGeo& g) {
 template <int PREC, int CKT, int KS, int STRIDE, int TH, int TW, int WAVES, int MI>
 static int launch_ni(const ConvK& k, int NI, dim3 grid, size_t lds, hipStream_t s) {
     dim3 block(WAVES * 64);
-    if (CKT == 32 && PREC != CCDM_PREC_F32) {       // small-spatial CK=32 variant always runs one n-tile per block
+    if constexpr (TW < 32 || (CKT == 32 && PREC != CCDM_PREC_F32)) {       // narrow tiles always run one n-tile per block (launch_conv)
         hipLaunchKernelGGL((k_conv<PREC, CKT, KS, STRIDE, TH, TW, WAVES, MI, 1>), grid, block, lds, s, k);
-        return 0;
-    }
-    switch (NI) {
-        case 1: hipLaunchKernelGGL((k_conv<PREC, CKT, KS, STRIDE, TH, TW, WAVES, MI, 1>), grid, block, lds, s, k); break;
-        case 2: hipLaunchKernelGGL((k_conv<PREC, CKT, KS, STRIDE, TH, TW, WAVES, MI, 2>), grid, block, lds, s, k); break;
-        case 3: hipLaunchKernelGGL((k_conv<PREC, CKT, KS, STRIDE, TH, TW, WAVES, MI, 3>), grid, block, lds, s, k); break;
-        case 4: hipLaunchKernelGGL((k_conv<PREC, CKT, KS, STRIDE, TH, TW, WAVES, MI, 4>), grid, block, lds, s, k); break;
-        default: return fail("conv: bad NI %d", NI);
+    } else {
+        switch (NI) {
+            case 1: hipLaunchKernelGGL((k_conv<PREC, CKT, KS, STRIDE, TH, TW, WAVES, MI, 1>), grid, block, lds, s, k); break;
+            case 2: hipLaunchKernelGGL((k_conv<PREC, CKT, KS, STRIDE, TH, TW, WAVES, MI, 2>), grid, block, lds, s, k); break;
+            default: return fail("conv: bad NI %d", NI);
+        }
     }
     return 0;
 }

@@ -11,6 +11,24 @@ __device__ __forceinline__ float silu_fast(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
 }
 
+// Load 16 bytes from global memory at (wave-uniform pointer + 32-bit per-lane byte offset).  The pointer is passed
+// through readfirstlane so the compiler must keep it in scalar registers and select the saddr + voffset addressing
+// form: no 64-bit vector adds, one VGPR of address per load.
+typedef const __attribute__((address_space(1))) char* gptr_t;
+__device__ __forceinline__ f32x4 load16_uniform_base(const char* base, unsigned voff) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(base);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    gptr_t g = reinterpret_cast<gptr_t>(((unsigned long long)hi << 32) | lo);
+    return *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(g + voff);
+}
+
+__device__ __forceinline__ void store16_uniform_base(char* base, unsigned voff, const f32x4 v) {
+    const unsigned long long u = reinterpret_cast<unsigned long long>(base);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    __attribute__((address_space(1))) char* g = reinterpret_cast<__attribute__((address_space(1))) char*>(((unsigned long long)hi << 32) | lo);
+    *reinterpret_cast<__attribute__((address_space(1))) f32x4*>(g + voff) = v;
+}
+
 struct ConvK {   // kernel-side copy of ccdm_conv_args (+ derived)
     ccdm_conv_args a;
     int cin_pad, ntiles, slices, tiles_x, tiles_y;
