@@ -46,7 +46,7 @@ template <int PREC, int CKT> struct Lds {
     static constexpr int PIXB = PREC == CCDM_PREC_F32 ? 33 * 4 : CKT * 4 + 16;
 };
 
-// (ACT_PRESCALE, silu_fast, ConvK, compute_gn_affine: ccdm_conv_common.h)
+// (ACT_PRESCALE, ConvK, compute_gn_affine, load16/store16_uniform_base: ccdm_conv_common.h)
 
 // register budget: >= 3 waves per SIMD (<= 168 VGPRs) when the accumulator tile is small — matches the 3 blocks
 // per CU the LDS footprint (A tile 27 KB + B chunk 18 KB) admits
@@ -283,31 +283,42 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
         const int tq = t_ % QPP, px = (t_ / QPP) % TW;
         float2 t0 = make_float2(1.f, 0.f), t1 = t0, t2 = t0, t3 = t0;
         if (GN) { const int c = c0 + 4 * tq; t0 = ab[c]; t1 = ab[c + 1]; t2 = ab[c + 2]; t3 = ab[c + 3]; }
+        // F16X3: activations are pre-scaled by 2^4 (exact; undone through the weight-scale table) so that the lo half of values
+        // down to ~2e-3 stays in fp16's normal range.  The factor rides along for free: folded into the GroupNorm affine
+        // when there is no activation, into the sigmoid's reciprocal when there is (16/(1+e) = 1/(2^-4 + e*2^-4), exact
+        // rescaling of the same roundings).
+        constexpr bool F16 = PREC != CCDM_PREC_F32;
+        constexpr float PS = F16 ? ACT_PRESCALE : 1.0f;
+        if (GN && !ACT && F16) { t0.x *= PS; t0.y *= PS; t1.x *= PS; t1.y *= PS; t2.x *= PS; t2.y *= PS; t3.x *= PS; t3.y *= PS; }
+        auto act = [&](const float x) {
+            if (!ACT) return (GN || !F16) ? x : x * PS;
+            // x * sigmoid(x) * PS with v_exp_f32 / v_rcp_f32 (1 ulp each); limits: x -> -inf gives -0, x -> +inf gives PS*x
+            return x * __builtin_amdgcn_rcpf(1.0f / PS + __builtin_amdgcn_exp2f(fmaf(x, -1.4426950408889634f, F16 ? -4.0f : 0.0f)));
+        };
+        static_assert(ACT_PRESCALE == 16.0f, "the exp2 bias above is log2(ACT_PRESCALE)");
         auto put = [&](const f32x4 r, const bool ok, const int hp) {
             float4 v = make_float4(r[0], r[1], r[2], r[3]);
             if (GN) { v.x = fmaf(v.x, t0.x, t0.y); v.y = fmaf(v.y, t1.x, t1.y); v.z = fmaf(v.z, t2.x, t2.y); v.w = fmaf(v.w, t3.x, t3.y); }
-            if (ACT) { v.x = silu_fast(v.x); v.y = silu_fast(v.y); v.z = silu_fast(v.z); v.w = silu_fast(v.w); }
+            v.x = act(v.x); v.y = act(v.y); v.z = act(v.z); v.w = act(v.w);
             if (PREC == CCDM_PREC_F32) {
                 float* d = halo + hp * 33 + 4 * tq;
                 d[0] = ok ? v.x : 0.f; d[1] = ok ? v.y : 0.f; d[2] = ok ? v.z : 0.f; d[3] = ok ? v.w : 0.f;
             } else {
-                // fp16 hi/lo split: x = hi + lo + O(2^-22 |x|); both halves round-to-nearest
-                // (saturate at fp16's largest finite value instead of producing inf: |x| up to 1.3e5 then still splits
-                //  exactly into hi + lo, beyond that the operand clips — raw residual-stream inputs are unbounded in principle)
-                // Activations are pre-scaled by 2^4 (exact; undone through the weight-scale table) so that the lo half of
-                // values down to ~2e-3 stays in fp16's normal range; full split precision holds for 2e-3 <= |x| <= 4094.
-                v.x = __builtin_amdgcn_fmed3f(v.x * ACT_PRESCALE, -65504.f, 65504.f); v.y = __builtin_amdgcn_fmed3f(v.y * ACT_PRESCALE, -65504.f, 65504.f);
-                v.z = __builtin_amdgcn_fmed3f(v.z * ACT_PRESCALE, -65504.f, 65504.f); v.w = __builtin_amdgcn_fmed3f(v.w * ACT_PRESCALE, -65504.f, 65504.f);
+                // fp16 hi/lo split: x = hi + lo + O(2^-22 |x|); both halves round-to-nearest; full split precision holds for
+                // 2e-3 <= |x| <= 4094.  Values are saturated at fp16's largest finite value instead of producing inf (|x| up to
+                // 1.3e5 then still splits exactly into hi + lo, beyond that the operand clips — raw residual-stream inputs are
+                // unbounded in principle).  The same clamp zeroes padding: its bound is 0 there (one select per item, and
+                // lo = 0 - 0 follows).
+                const float lim = ok ? 65504.f : 0.f;
+                v.x = __builtin_amdgcn_fmed3f(v.x, -lim, lim); v.y = __builtin_amdgcn_fmed3f(v.y, -lim, lim);
+                v.z = __builtin_amdgcn_fmed3f(v.z, -lim, lim); v.w = __builtin_amdgcn_fmed3f(v.w, -lim, lim);
                 f16x4 hi, lo;
                 hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
                 lo[0] = (_Float16)(v.x - (float)hi[0]); lo[1] = (_Float16)(v.y - (float)hi[1]);
                 lo[2] = (_Float16)(v.z - (float)hi[2]); lo[3] = (_Float16)(v.w - (float)hi[3]);
-                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                u32x2 hb = __builtin_bit_cast(u32x2, hi), lb = __builtin_bit_cast(u32x2, lo);
-                hb[0] = ok ? hb[0] : 0u; hb[1] = ok ? hb[1] : 0u; lb[0] = ok ? lb[0] : 0u; lb[1] = ok ? lb[1] : 0u;
                 char* d = halo_b + hp * PIXB + 8 * tq;
-                *reinterpret_cast<u32x2*>(d) = hb;
-                *reinterpret_cast<u32x2*>(d + 2 * CK) = lb;
+                *reinterpret_cast<f16x4*>(d) = hi;
+                *reinterpret_cast<f16x4*>(d + 2 * CK) = lo;
             }
         };
         if constexpr (ROWS) {
@@ -367,11 +378,11 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
         }
         CCDM_STAMP(2);
         if (!(dbg & 4)) issueB(it);
-        __syncthreads();          // previous MFMA phase has finished reading LDS (and ab[] is visible)
+        if (!(dbg & 256)) __syncthreads();          // previous MFMA phase has finished reading LDS (and ab[] is visible)
         CCDM_STAMP(3);
         if (!(dbg & 2)) commit(it);
         CCDM_STAMP(4);
-        __syncthreads();
+        if (!(dbg & 256)) __syncthreads();
         CCDM_STAMP(5);
         if (!(dbg & 4)) issue(it + 1 < n_iter ? it + 1 : it);    // next tile-chunk's HBM reads fly during the MFMA phase (the last one re-reads its own: harmless, branch-free)
 
@@ -454,7 +465,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
             if (fast_epi) {
                 // ---- fast path: accumulators -> wave-private LDS rows [pixel][32 ch] -> float4 per lane
                 //      (8 lanes cover one pixel's 128-byte row: residual loads and stores move 16 B per lane) ----
-                __syncthreads();                                   // every wave is done reading the A/B tiles
+                if (!(dbg & 256)) __syncthreads();                 // every wave is done reading the A/B tiles
                 const int cq = lane_ & 7, prow = lane_ >> 3;
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
@@ -769,6 +780,8 @@ int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
     const size_t epi = (size_t)g.waves * ksp * g.MI * 32 * 36 * 4;        // epilogue transpose buffer (wave-private rows)
     if (lds < epi) lds = epi;
     if (a.stats0) lds += (size_t)C * 8;
+    if ((a.prec >> 8) & 512) lds = 60 * 1024;      // diagnostics (tools/bench_conv.py): at most 2 blocks per CU
+    if ((a.prec >> 8) & 1024) lds = 100 * 1024;    //                                   1 block per CU
     CCDM_REQUIRE(lds <= 160 * 1024, "conv: LDS %zu too large", lds);
     dim3 grid(a.N * k.slices, k.ntiles / NI);
     const int rc = prec == CCDM_PREC_F32 ? launch_prec<CCDM_PREC_F32>(k, g, NI, ck, grid, lds, s)

@@ -6,11 +6,6 @@ namespace ccdm {
 
 static constexpr float ACT_PRESCALE = 16.0f;       // F16X3 activation pre-scale (power of two)
 
-__device__ __forceinline__ float silu_fast(float x) {
-    // x * sigmoid(x) with v_exp_f32 / v_rcp_f32 (1 ulp each); limits: x -> -inf gives -0, x -> +inf gives x
-    return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
-}
-
 // Load 16 bytes from global memory at (wave-uniform pointer + 32-bit per-lane byte offset).  The pointer is passed
 // through readfirstlane so the compiler must keep it in scalar registers and select the saddr + voffset addressing
 // form: no 64-bit vector adds, one VGPR of address per load.
@@ -28,7 +23,6 @@ __device__ __forceinline__ void store16_uniform_base(char* base, unsigned voff, 
     __attribute__((address_space(1))) char* g = reinterpret_cast<__attribute__((address_space(1))) char*>(((unsigned long long)hi << 32) | lo);
     *reinterpret_cast<__attribute__((address_space(1))) f32x4*>(g + voff) = v;
 }
-
 struct ConvK {   // kernel-side copy of ccdm_conv_args (+ derived)
     ccdm_conv_args a;
     int cin_pad, ntiles, slices, tiles_x, tiles_y;
