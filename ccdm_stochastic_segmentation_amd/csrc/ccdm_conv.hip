@@ -31,9 +31,19 @@
 
 namespace ccdm {
 
+// Ablation / timeline switches (bits 8.. of `prec`, used by tools/bench_conv.py) exist only in a -DCCDM_ABLATION build
+// (CCDM_ABLATION=1 python -c "from ccdm_stochastic_segmentation_amd import hip; hip.build()"): as run-time tests they put
+// a branch around every store and every phase of the production kernel.
+//   1 no MFMA | 2 no commit | 4 no loads | 8 no stores | 16 phase timeline | 256 no barriers (wrong results)
+//   512 / 1024: pad the LDS request so that at most 2 / 1 blocks fit a CU (host side, always available)
+#ifdef CCDM_ABLATION
+#define CCDM_DBG(bit) ((dbg & (bit)) != 0)
+#else
+#define CCDM_DBG(bit) false
+#endif
 // phase timeline of one block (ablation bit 16 of prec; read back with ccdm_debug_read_timeline)
 __device__ unsigned long long g_timeline[1024];
-#define CCDM_STAMP(slot) do { if ((dbg & 16) && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && tid == 0 && tl < 1020) \
+#define CCDM_STAMP(slot) do { if (CCDM_DBG(16) && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && tid == 0 && tl < 1020) \
         g_timeline[tl++] = ((unsigned long long)(slot) << 56) | (__builtin_amdgcn_s_memtime() & 0x00ffffffffffffffull); } while (0)
 
 // F32  : CK = 32 channels per chunk; LDS pixel = 33 floats (odd stride: conflict-free column reads).
@@ -117,7 +127,8 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
     const int step = a.step_ptr ? *a.step_ptr : 0;
     const int emb_row = (a.emb_row_of_sample ? a.emb_row_of_sample[n] : 0) + step;
     const bool has_gn = a.stats0 != nullptr;
-    const int dbg = a.prec >> 8;          // ablation switches for tools/bench_conv.py (0 in production)
+    const int dbg = a.prec >> 8;          // ablation switches for tools/bench_conv.py (CCDM_ABLATION builds only)
+    (void)dbg;
 
     if (has_gn) compute_gn_affine(a, n, emb_row, ab);
     const int aWout = a.Wout, aCout = a.Cout, aHout = a.Hout, aWin = a.Win;
@@ -142,6 +153,22 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
 #pragma unroll
         for (int j = 0; j < 4; ++j) { s1[ni][j] = 0.f; s2[ni][j] = 0.f; }
     const bool fast_epi = (a.Cout & 3) == 0;       // uniform: float4 rows through an LDS transpose
+    // per-lane epilogue constants of output channel (n-tile, lane & 31): bias (+ emb row) and the power of two that undoes
+    // the weight / activation pre-scales.  Fetched once per block — inside the tile loop their L2 latency sat in every
+    // epilogue's critical path.
+    float epi_add[NI], epi_wsc[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int co = (nt0 + ni) * 32 + (lane & 31);
+        epi_add[ni] = 0.f; epi_wsc[ni] = 1.0f;
+        if (co < a.Cout) {
+            if (krow == 0) {                        // bias (+emb) enters once, through row group 0's partial
+                epi_add[ni] = a.bias ? a.bias[co] : 0.f;
+                if (a.emb_off >= 0) epi_add[ni] += a.emb_table[(size_t)emb_row * a.emb_stride + a.emb_off + co];   // (conv + bias) + emb == conv + (bias + emb) up to 1 ulp
+            }
+            if (PREC != CCDM_PREC_F32) epi_wsc[ni] = k.wscale[co];        // exact power of two
+        }
+    }
     constexpr int EPS = 36;                        // floats per pixel row of the transpose buffer (16-B aligned rows)
     float* epi = reinterpret_cast<float*>(halo_b) + wave_all * (MI * 32 * EPS);      // [krow][wave][MI*32][EPS]
 
@@ -377,19 +404,19 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                     for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
         }
         CCDM_STAMP(2);
-        if (!(dbg & 4)) issueB(it);
-        if (!(dbg & 256)) __syncthreads();          // previous MFMA phase has finished reading LDS (and ab[] is visible)
+        if (!CCDM_DBG(4)) issueB(it);
+        if (!CCDM_DBG(256)) __syncthreads();          // previous MFMA phase has finished reading LDS (and ab[] is visible)
         CCDM_STAMP(3);
-        if (!(dbg & 2)) commit(it);
+        if (!CCDM_DBG(2)) commit(it);
         CCDM_STAMP(4);
-        if (!(dbg & 256)) __syncthreads();
+        if (!CCDM_DBG(256)) __syncthreads();
         CCDM_STAMP(5);
-        if (!(dbg & 4)) issue(it + 1 < n_iter ? it + 1 : it);    // next tile-chunk's HBM reads fly during the MFMA phase (the last one re-reads its own: harmless, branch-free)
+        if (!CCDM_DBG(4)) issue(it + 1 < n_iter ? it + 1 : it);    // next tile-chunk's HBM reads fly during the MFMA phase (the last one re-reads its own: harmless, branch-free)
 
         CCDM_STAMP(6);
         const bool skc = chunk >= nchunk_main;                   // uniform
         const int c0 = (skc ? chunk - nchunk_main : chunk) * CK;
-        if (dbg & 1) {
+        if (CCDM_DBG(1)) {
         } else if (PREC == CCDM_PREC_F32) {
             // taps x 16 k-steps of v_mfma_f32_32x32x2_f32; B: [tap][cin_pad/2][ntiles][64] floats
             const float* wc = reinterpret_cast<const float*>(skc ? a.skip_w : a.w) + ((size_t)(c0 >> 1) * k.ntiles + nt0) * 64 + lane;
@@ -419,39 +446,65 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
             // (the skip segment's single centre tap is its own copy), so the LDS reads of the next tap are scheduled
             // under the MFMAs of the current one.
             const f16x8* bq = reinterpret_cast<const f16x8*>(ldsB) + lane;
-            auto tap_mfma = [&](const int toff, const int bt) {
+            // One step = one (tap, 16-channel k-step): 2*MI A fragments + 2*NI B fragments from LDS, 3*MI*NI MFMAs.
+            // The fragments of step s+1 are requested before the MFMAs of step s are issued (two register sets, static
+            // indices after unrolling): the LDS round trip — ~130+ cycles that an in-order wave otherwise spends idle
+            // in front of every tap — runs under the previous step's matrix work.
+            constexpr bool PF = MI * NI <= 2;          // the second fragment set fits the register budget
+            f16x8 ah[2][MI], al[2][MI], bh[2][NI], bl[2][NI];
+            auto frag_load = [&](const int buf, const int toff, const int bt, const int ks) {
 #pragma unroll
-                for (int ks = 0; ks < KST; ++ks) {
-                    f16x8 ah[MI], al[MI];
+                for (int mi = 0; mi < MI; ++mi) {
+                    const char* p = halo_b + base[mi] + toff + 32 * ks;
+                    ah[buf][mi] = *reinterpret_cast<const f16x8*>(p);
+                    al[buf][mi] = *reinterpret_cast<const f16x8*>(p + 2 * CK);
+                }
 #pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) {
-                        const char* p = halo_b + base[mi] + toff + 32 * ks;
-                        ah[mi] = *reinterpret_cast<const f16x8*>(p);
-                        al[mi] = *reinterpret_cast<const f16x8*>(p + 2 * CK);
+                for (int ni = 0; ni < NI; ++ni) {
+                    bh[buf][ni] = bq[((bt * KST + ks) * NI + ni) * 128];
+                    bl[buf][ni] = bq[((bt * KST + ks) * NI + ni) * 128 + 64];
+                }
+            };
+            auto frag_mfma = [&](const int buf) {
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[buf][mi], bh[buf][ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[buf][mi], bl[buf][ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[buf][mi], bh[buf][ni], acc[mi][ni], 0, 0, 0);
+                }
+            };
+            // walk(NTAP, tap -> (toff, bt)): NTAP*KST steps, software-pipelined one step deep
+            auto walk = [&](auto NTAP_, auto&& toff_of, auto&& bt_of) {
+                constexpr int NSTEP = decltype(NTAP_)::value * KST;
+                if constexpr (PF) {
+                    frag_load(0, toff_of(0), bt_of(0), 0);
+#pragma unroll
+                    for (int st = 0; st < NSTEP; ++st) {
+                        if (st + 1 < NSTEP) frag_load((st + 1) & 1, toff_of((st + 1) / KST), bt_of((st + 1) / KST), (st + 1) % KST);
+                        __builtin_amdgcn_sched_barrier(0);      // keep the requests in front of the MFMAs (the scheduler sinks them to save registers)
+                        frag_mfma(st & 1);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
+                } else {
 #pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) {
-                        const f16x8 bh = bq[((bt * KST + ks) * NI + ni) * 128];
-                        const f16x8 bl = bq[((bt * KST + ks) * NI + ni) * 128 + 64];
-#pragma unroll
-                        for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh, acc[mi][ni], 0, 0, 0);
-#pragma unroll
-                        for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl, acc[mi][ni], 0, 0, 0);
-#pragma unroll
-                        for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh, acc[mi][ni], 0, 0, 0);
+                    for (int st = 0; st < NSTEP; ++st) {
+                        frag_load(0, toff_of(st / KST), bt_of(st / KST), st % KST);
+                        frag_mfma(0);
                     }
                 }
             };
             if (skc) {
                 // skip segment: centre tap only, its weights are staged as B slot 0 (tap split: the centre row's group)
-                if (KSP == 1 || krow == KS / 2) tap_mfma((PAD * HWt + PAD) * PIXB, 0);
+                if (KSP == 1 || krow == KS / 2)
+                    walk(std::integral_constant<int, 1>{}, [&](int) { return (PAD * HWt + PAD) * PIXB; }, [&](int) { return 0; });
             } else if (KSP > 1) {
                 // tap split: this wave group owns kernel row `krow`
-#pragma unroll
-                for (int u = 0; u < KS; ++u) tap_mfma((krow * HWt + u) * PIXB, krow * KS + u);
+                walk(std::integral_constant<int, KS>{}, [&](int u) { return (krow * HWt + u) * PIXB; }, [&](int u) { return krow * KS + u; });
             } else {
-#pragma unroll
-                for (int tap = 0; tap < KS * KS; ++tap) tap_mfma(((tap / KS) * HWt + (tap % KS)) * PIXB, tap);
+                walk(std::integral_constant<int, KS * KS>{}, [&](int tap) { return ((tap / KS) * HWt + (tap % KS)) * PIXB; }, [&](int tap) { return tap; });
             }
         }
 
@@ -465,7 +518,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
             if (fast_epi) {
                 // ---- fast path: accumulators -> wave-private LDS rows [pixel][32 ch] -> float4 per lane
                 //      (8 lanes cover one pixel's 128-byte row: residual loads and stores move 16 B per lane) ----
-                if (!(dbg & 256)) __syncthreads();                 // every wave is done reading the A/B tiles
+                if (!CCDM_DBG(256)) __syncthreads();                 // every wave is done reading the A/B tiles
                 const int cq = lane_ & 7, prow = lane_ >> 3;
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
@@ -479,7 +532,8 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                     const bool full = oy0 + TH <= aHout && ox0 + TW <= aWout && (nt0 + ni) * 32 + 32 <= aCout;   // uniform
                     constexpr int RS_FIRST = MI * 4 > 4 ? 4 : MI * 4;
                     f32x4 rs[MI * 4];
-                    const unsigned lane_off = ((unsigned)prow * (unsigned)aCout + (unsigned)co4) << 2;
+                    unsigned lane_off = ((unsigned)prow * (unsigned)aCout + (unsigned)co4) << 2;
+                    asm volatile("" : "+v"(lane_off));      // stays a 32-bit offset (hoisted out of the tile loop it becomes a 64-bit pair and the saddr form is lost)
                     auto row_of = [&](const int j) { return oy0 + wave * (MI * 32 / TW) + (j * 8) / TW; };       // uniform
                     auto row_base = [&](const int j) {      // byte offset of pixel (oy, ox0 + cx), channel 0, within the sample
                         return (unsigned)((row_of(j) * aWout + ox0 + (j * 8) % TW) * aCout) << 2;
@@ -505,15 +559,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                     };
                     if (RESID) load_resid(0, RS_FIRST);
                     {
-                        const int co = (nt0 + ni) * 32 + (lane_ & 31);
-                        float add = 0.f, wsc = 1.0f;
-                        if (co < a.Cout) {
-                            if (krow == 0) {                        // bias (+emb) enters once, through row group 0's partial
-                                add = a.bias ? a.bias[co] : 0.f;
-                                if (a.emb_off >= 0) add += a.emb_table[(size_t)emb_row * a.emb_stride + a.emb_off + co];
-                            }
-                            if (PREC != CCDM_PREC_F32) wsc = k.wscale[co];
-                        }
+                        const float add = epi_add[ni], wsc = epi_wsc[ni];
 #pragma unroll
                         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -536,13 +582,13 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                                 v += *reinterpret_cast<const f32x4*>(epi0 + g * (WAVES * MI * 32 * EPS) + pl * EPS + 4 * cq);
                             if (RESID) v += rs[j];
                             if (FULL) {
-                                if (!(dbg & 8)) store16_uniform_base(reinterpret_cast<char*>(outn) + row_base(j), lane_off, v);
+                                if (!CCDM_DBG(8)) store16_uniform_base(reinterpret_cast<char*>(outn) + row_base(j), lane_off, v);
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) { t1[e] += v[e]; t2[e] = fmaf(v[e], v[e], t2[e]); }
                             } else {
                                 const int oy = row_of(j), ox = ox0 + (j * 8) % TW + prow;
                                 if (cv4 && oy < aHout && ox < aWout) {
-                                    if (!(dbg & 8))
+                                    if (!CCDM_DBG(8))
                                         *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(outn) +
                                                                   (((unsigned)(oy * aWout + ox) * (unsigned)aCout + (unsigned)co4) << 2)) = v;
 #pragma unroll
@@ -563,12 +609,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
             for (int ni = 0; ni < NI; ++ni) {
                 const int co = (nt0 + ni) * 32 + (lane_ & 31);
                 const bool cv = co < a.Cout;
-                float add = 0.f, wsc = 1.0f;
-                if (cv) {
-                    add = a.bias ? a.bias[co] : 0.f;
-                    if (PREC != CCDM_PREC_F32) wsc = k.wscale[co];        // exact power of two
-                    if (a.emb_off >= 0) add += a.emb_table[(size_t)emb_row * a.emb_stride + a.emb_off + co];   // (conv + bias) + emb == conv + (bias + emb) up to 1 ulp
-                }
+                const float add = epi_add[ni], wsc = epi_wsc[ni];
                 // per-tile partial statistics in fp32 (<= 32 values per lane), folded into the fp64 running sums once per tile
                 float t1 = 0.f, t2 = 0.f;
 #pragma unroll
@@ -583,7 +624,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                             const size_t idx = ((size_t)(n * a.Hout + oy) * a.Wout + ox) * a.Cout + co;
                             float v = (PREC == CCDM_PREC_F32 ? acc[mi][ni][r] : acc[mi][ni][r] * wsc) + add;
                             if (a.resid) v += a.resid[idx];
-                            if (!(dbg & 8)) a.out[idx] = v;
+                            if (!CCDM_DBG(8)) a.out[idx] = v;
                             t1 += v;
                             t2 = fmaf(v, v, t2);
                         }
@@ -597,7 +638,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
     }
 
     CCDM_STAMP(8);
-    if ((dbg & 16) && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && tid == 0) g_timeline[1023] = tl;
+    if (CCDM_DBG(16) && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && tid == 0) g_timeline[1023] = tl;
     if (a.out_stats) {
         // fold the lanes that hold the same channel, then the block's waves; fixed order everywhere
         __syncthreads();

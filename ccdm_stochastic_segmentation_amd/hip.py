@@ -104,7 +104,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     deps = srcs + [os.path.join(CSRC, "ccdm_common.h"), os.path.join(CSRC, "ccdm_conv_common.h"), os.path.join(ROOT, "include", "ccdm_hip.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
-    cmd = ["hipcc", *HIPCC_FLAGS, "-I" + os.path.join(ROOT, "include"), *srcs, "-o", LIB_PATH]
+    extra = ["-DCCDM_ABLATION"] if os.environ.get("CCDM_ABLATION") else []      # tools/bench_conv.py ABLATE / TIMELINE modes
+    cmd = ["hipcc", *HIPCC_FLAGS, *extra, "-I" + os.path.join(ROOT, "include"), *srcs, "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -77,7 +77,7 @@ def run(prec, shape, iters=20, dbg=0):
 def timeline(prec, shape):
     """Phase durations (cycles) of one mid-grid block: stamps 2..7 per iteration = loop top | barrier A | commit | barrier B |
     issue | MFMA phase | (epilogue)."""
-    run(prec, shape, iters=1, dbg=16)
+    run(prec, shape, iters=1, dbg=16 | int(os.environ.get("TLDBG", "0")))
     lib = hip.load()
     buf = (C.c_ulonglong * 1024)()
     hip.check(lib.ccdm_debug_read_timeline(buf, 1024))
