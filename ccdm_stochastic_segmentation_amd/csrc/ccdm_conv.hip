@@ -192,19 +192,35 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
     // B staging: slab within a pass (wave-uniform: G >= 128 lanes), item within the slab
     const unsigned tgB = B_MULTI ? (unsigned)__builtin_amdgcn_readfirstlane(tid / G) : 0u;
 
-    // ---- issue: global -> registers for iteration `it` (tile, chunk) ----
-    auto issue = [&](int it) {
-        const int tile = slice + (it / nchunk) * k.slices;
-        const int ch = it % nchunk;
-        const bool sk = ch >= nchunk_main;                       // uniform: this chunk belongs to the skip segment
+    // Per-chunk descriptors, one chunk per LANE of a few registers (lane c = chunk c; read back with v_readlane and a
+    // scalar chunk index): the source tensor's per-sample base pointer, its channel count and the chunk's first channel
+    // within it, the chunk's weight-fragment base.  Built once; the loop then selects a chunk's operands with five
+    // readlanes instead of re-deriving them (selects over kernel-argument fields, 64-bit multiplies, scalar loads).
+    unsigned T_lo = 0, T_hi = 0, T_cc = 0, T_wlo = 0, T_whi = 0;
+    {
+        const int ch = lane < nchunk ? lane : 0;
+        const bool sk = ch >= nchunk_main;                       // this chunk belongs to the fused 1x1 skip segment
         const int c0 = (sk ? ch - nchunk_main : ch) * CK;
         const int sC0 = sk ? a.SC0 : a.C0, sC1 = sk ? a.SC1 : a.C1;
         // a chunk never straddles the concat seam (launcher: C0 % CK == 0 when there is a second source)
-        const bool second = sC1 > 0 && c0 >= sC0;                 // uniform
+        const bool second = sC1 > 0 && c0 >= sC0;
         const int Cs = second ? sC1 : sC0, cb = second ? c0 - sC0 : c0;
         const float* srcsel = sk ? (second ? a.skip1 : a.skip0) : (second ? a.in1 : a.in0);
-        const char* srcb = reinterpret_cast<const char*>(srcsel + (size_t)n * (sk ? out_px : in_px) * Cs);   // uniform per-sample base
-        const int oy0 = (tile / k.tiles_x) * TH, ox0 = (tile % k.tiles_x) * TW;
+        const unsigned long long sb = reinterpret_cast<unsigned long long>(srcsel + (size_t)n * (sk ? out_px : in_px) * Cs);
+        T_lo = (unsigned)sb; T_hi = (unsigned)(sb >> 32);
+        T_cc = (unsigned)Cs | ((unsigned)cb << 16);
+        const unsigned long long wb = reinterpret_cast<unsigned long long>(sk ? a.skip_w : a.w) + (((size_t)(c0 >> 4) * k.ntiles + nt0) * 128 << 4);
+        T_wlo = (unsigned)wb; T_whi = (unsigned)(wb >> 32);
+    }
+
+    // ---- issue: global -> registers for iteration `it` (tile, chunk) ----
+    auto issue = [&](const int ch, const int ty, const int tx) {
+        const unsigned cc = __builtin_amdgcn_readlane(T_cc, ch);
+        const int Cs = cc & 0xffffu, cb = cc >> 16;
+        const char* srcb = reinterpret_cast<const char*>(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(T_hi, ch) << 32) |
+                                                         (unsigned)__builtin_amdgcn_readlane(T_lo, ch));      // uniform per-sample base
+        const int ups = __builtin_amdgcn_readfirstlane(a.up);   // scalar shift amount (in a vector register the row math below turns vector too)
+        const int oy0 = ty * TH, ox0 = tx * TW;
         // Every load is issued unconditionally with its address clamped into the tensor; padding is zeroed at commit.
         // (A conditional load would put a control-flow join between the prefetch and the MFMA phase, and the waitcnt
         //  pass then drains the whole prefetch (vmcnt(0)) at the join.)
@@ -220,7 +236,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                 const int ix = ox0 + px;                                           // core columns: halo x = px + PAD
                 xok = cok & (ix < Wc);
                 const int ixc = min(ix, Wc - 1);
-                const unsigned colb = ((unsigned)(a.up ? ixc >> 1 : ixc) * (unsigned)Cs + cq) << 2;
+                const unsigned colb = ((unsigned)(ixc >> ups) * (unsigned)Cs + cq) << 2;
                 rowmask = 0;
 #pragma unroll
                 for (int i = 0; i < NCORE; ++i) {
@@ -228,7 +244,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                     const int iy = oy0 - PAD + row;
                     const bool rok = ((unsigned)iy < (unsigned)Hc) & ((i + 1) * RPP <= HHt || row < HHt);
                     const int iyc = min(max(iy, 0), Hc - 1);
-                    const unsigned sy = (unsigned)(a.up ? iyc >> 1 : iyc);
+                    const unsigned sy = (unsigned)(iyc >> ups);
                     if constexpr (ROW_UNIFORM) reg[i] = load16_uniform_base(srcb + (size_t)(sy * rowb), colb);
                     else reg[i] = *reinterpret_cast<const f32x4*>(srcb + (sy * rowb + colb));
                     rowmask |= (rok ? 1u : 0u) << i;
@@ -243,7 +259,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                 const int iy = oy0 - PAD + (int)row, ix = ox0 - PAD + hx;
                 const bool ok = cok & (e < (unsigned)EDGE_ITEMS) & ((unsigned)iy < (unsigned)Hc) & ((unsigned)ix < (unsigned)Wc);
                 const int iyc = min(max(iy, 0), Hc - 1), ixc = min(max(ix, 0), Wc - 1);
-                const unsigned sy = (unsigned)(a.up ? iyc >> 1 : iyc), sx = (unsigned)(a.up ? ixc >> 1 : ixc);
+                const unsigned sy = (unsigned)(iyc >> ups), sx = (unsigned)(ixc >> ups);
                 reg[NCORE + j] = *reinterpret_cast<const f32x4*>(srcb + (size_t)(sy * rowb + ((sx * (unsigned)Cs + cq) << 2)));
                 evalid |= (ok ? 1u : 0u) << j;
             }
@@ -264,7 +280,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                 // padding test: unsigned compare folds the < 0 and >= extent checks; no short-circuit branches
                 const bool ok = cok & ((unsigned)iy < (unsigned)Hc) & ((unsigned)ix < (unsigned)Wc) & (hy < (unsigned)HHt);
                 const int iyc = min(max(iy, 0), Hc - 1), ixc = min(max(ix, 0), Wc - 1);
-                const int sy = a.up ? (iyc >> 1) : iyc, sx = a.up ? (ixc >> 1) : ixc;
+                const int sy = iyc >> ups, sx = ixc >> ups;
                 const unsigned off = ((unsigned)(sy * aWin + sx) * (unsigned)Cs + cq) << 2;      // bytes within the sample
                 reg[i] = *reinterpret_cast<const f32x4*>(srcb + off);
                 valid |= (ok ? 1u : 0u) << i;
@@ -276,16 +292,15 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
     // ---- issueB: this chunk's weight fragments, global (L2-resident) -> registers.  Requested at the top of the
     //      iteration that consumes them — their (short) latency hides behind the commit's arithmetic — so that they
     //      do not occupy 4*NITEM_B registers across the MFMA phase and the epilogue like the halo prefetch does.
-    auto issueB = [&](int it) {
-        const int ch = it % nchunk;
+    auto issueB = [&](const int ch) {
         const bool sk = ch >= nchunk_main;
-        const int c0 = (sk ? ch - nchunk_main : ch) * CK;
         unsigned t_ = tid;
         asm volatile("" : "+v"(t_));
         if (PREC != CCDM_PREC_F32) {
             // B chunk: [tap][k-step] slabs; skip chunks carry one tap (1x1): only their first KST slabs are meaningful,
             // the passes beyond re-read slab 0 (the load stays unconditional: regB[] stays in registers)
-            const char* wq = reinterpret_cast<const char*>(sk ? a.skip_w : a.w) + (((size_t)(c0 >> 4) * k.ntiles + nt0) * 128 << 4);
+            const char* wq = reinterpret_cast<const char*>(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(T_whi, ch) << 32) |
+                                                           (unsigned)__builtin_amdgcn_readlane(T_wlo, ch));
             const unsigned wtap = (unsigned)((sk ? k.cin_pad_skip : k.cin_pad) >> 4) * k.ntiles * 128;
             const unsigned wks = (unsigned)k.ntiles * 128;
             const unsigned nslab = sk ? KST : KS * KS * KST;
@@ -378,8 +393,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
             }
         }
     };
-    auto commit = [&](int it) {
-        const int ch = it % nchunk;
+    auto commit = [&](const int ch) {
         const bool sk = ch >= nchunk_main;
         const int c0 = (sk ? ch - nchunk_main : ch) * CK;
         const bool gn = has_gn && !sk, act = a.act == CCDM_ACT_SILU && !sk;
@@ -392,9 +406,19 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
     f32x16 acc[MI][NI];
     int tl = 0;
     CCDM_STAMP(1);
-    if (n_iter > 0) issue(0);
+    // (tile, chunk) walk of this block — tile = slice, slice + slices, ... — carried as scalar counters: the current
+    // iteration's (chunk, ty, tx) and, one step ahead, the prefetch's (no divisions in the loop)
+    const int adv_y = k.slices / k.tiles_x, adv_x = k.slices % k.tiles_x;
+    auto advance = [&](int& ch, int& ty, int& tx) {
+        if (++ch == nchunk) {
+            ch = 0; tx += adv_x; ty += adv_y;
+            if (tx >= k.tiles_x) { tx -= k.tiles_x; ++ty; }
+        }
+    };
+    int chunk = 0, cur_ty = slice / k.tiles_x, cur_tx = slice % k.tiles_x;
+    int pf_ch = 0, pf_ty = cur_ty, pf_tx = cur_tx;
+    if (n_iter > 0) { issue(pf_ch, pf_ty, pf_tx); advance(pf_ch, pf_ty, pf_tx); }
     for (int it = 0; it < n_iter; ++it) {
-        const int chunk = it % nchunk;
         if (chunk == 0) {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
@@ -404,14 +428,16 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                     for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
         }
         CCDM_STAMP(2);
-        if (!CCDM_DBG(4)) issueB(it);
+        if (!CCDM_DBG(4)) issueB(chunk);
         if (!CCDM_DBG(256)) __syncthreads();          // previous MFMA phase has finished reading LDS (and ab[] is visible)
         CCDM_STAMP(3);
-        if (!CCDM_DBG(2)) commit(it);
+        if (!CCDM_DBG(2)) commit(chunk);
         CCDM_STAMP(4);
         if (!CCDM_DBG(256)) __syncthreads();
         CCDM_STAMP(5);
-        if (!CCDM_DBG(4)) issue(it + 1 < n_iter ? it + 1 : it);    // next tile-chunk's HBM reads fly during the MFMA phase (the last one re-reads its own: harmless, branch-free)
+        // next tile-chunk's HBM reads fly during the MFMA phase (after the last iteration this requests a tile past the
+        // slice's last one: addresses are clamped into the tensor, the data is never committed — harmless, branch-free)
+        if (!CCDM_DBG(4)) { issue(pf_ch, pf_ty, pf_tx); advance(pf_ch, pf_ty, pf_tx); }
 
         CCDM_STAMP(6);
         const bool skc = chunk >= nchunk_main;                   // uniform
@@ -511,8 +537,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
         CCDM_STAMP(7);
         if (chunk == nchunk - 1) {
             // ---- epilogue: (x 2^-e) + bias (+ emb) (+ residual), store NHWC, accumulate output statistics ----
-            const int tile = slice + (it / nchunk) * k.slices;
-            const int oy0 = (tile / k.tiles_x) * TH, ox0 = (tile % k.tiles_x) * TW;
+            const int oy0 = cur_ty * TH, ox0 = cur_tx * TW;
             int lane_ = lane;
             asm volatile("" : "+v"(lane_));
             if (fast_epi) {
@@ -635,6 +660,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
             }
             }
         }
+        advance(chunk, cur_ty, cur_tx);
     }
 
     CCDM_STAMP(8);
@@ -812,6 +838,8 @@ int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
     if (a.out_stats) CCDM_REQUIRE(a.out_slices == k.slices, "conv: out_slices %d != %d", a.out_slices, k.slices);
     const int HP = ((g.TH - 1) * a.stride + a.ksize) * ((g.TW - 1) * a.stride + a.ksize);
     const int ck = chunk_ck(a, g);
+    CCDM_REQUIRE((k.cin_pad + k.cin_pad_skip) / ck <= 64, "conv: %d input (+%d skip) channels make more than 64 chunks of %d (chunk descriptors live in the 64 lanes of a register)",
+                 k.cin_pad, k.cin_pad_skip, ck);
     size_t lds = (size_t)HP * (prec == CCDM_PREC_F32 ? 33 * 4 : ck * 4 + 16);
     lds = (lds + 15) / 16 * 16;
     if (prec != CCDM_PREC_F32) lds += (size_t)a.ksize * a.ksize * (ck / 16) * NI * 128 * 16;     // staged B chunk
