@@ -36,6 +36,10 @@ namespace ccdm {
 // a branch around every store and every phase of the production kernel.
 //   1 no MFMA | 2 no commit | 4 no loads | 8 no stores | 16 phase timeline | 256 no barriers (wrong results)
 //   512 / 1024: pad the LDS request so that at most 2 / 1 blocks fit a CU (host side, always available)
+#ifndef CCDM_NT_STORES
+#define CCDM_NT_STORES 0
+#endif
+static constexpr bool NT_STORES = CCDM_NT_STORES != 0;     // experiment: outputs stored non-temporally
 #ifdef CCDM_ABLATION
 #define CCDM_DBG(bit) ((dbg & (bit)) != 0)
 #else
@@ -607,7 +611,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                                 v += *reinterpret_cast<const f32x4*>(epi0 + g * (WAVES * MI * 32 * EPS) + pl * EPS + 4 * cq);
                             if (RESID) v += rs[j];
                             if (FULL) {
-                                if (!CCDM_DBG(8)) store16_uniform_base(reinterpret_cast<char*>(outn) + row_base(j), lane_off, v);
+                                if (!CCDM_DBG(8)) store16_uniform_base<NT_STORES>(reinterpret_cast<char*>(outn) + row_base(j), lane_off, v);
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) { t1[e] += v[e]; t2[e] = fmaf(v[e], v[e], t2[e]); }
                             } else {

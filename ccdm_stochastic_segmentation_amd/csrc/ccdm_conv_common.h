@@ -17,11 +17,14 @@ __device__ __forceinline__ f32x4 load16_uniform_base(const char* base, unsigned 
     return *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(g + voff);
 }
 
+// NT: non-temporal (streaming) store — the line is marked evict-first in L2
+template <bool NT = false>
 __device__ __forceinline__ void store16_uniform_base(char* base, unsigned voff, const f32x4 v) {
     const unsigned long long u = reinterpret_cast<unsigned long long>(base);
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
     __attribute__((address_space(1))) char* g = reinterpret_cast<__attribute__((address_space(1))) char*>(((unsigned long long)hi << 32) | lo);
-    *reinterpret_cast<__attribute__((address_space(1))) f32x4*>(g + voff) = v;
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<__attribute__((address_space(1))) f32x4*>(g + voff));
+    else *reinterpret_cast<__attribute__((address_space(1))) f32x4*>(g + voff) = v;
 }
 struct ConvK {   // kernel-side copy of ccdm_conv_args (+ derived)
     ccdm_conv_args a;

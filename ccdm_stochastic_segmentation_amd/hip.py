@@ -105,6 +105,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     extra = ["-DCCDM_ABLATION"] if os.environ.get("CCDM_ABLATION") else []      # tools/bench_conv.py ABLATE / TIMELINE modes
+    extra += os.environ.get("CCDM_HIPCC_EXTRA", "").split()                     # experiments, e.g. -DCCDM_NT_STORES=1
     cmd = ["hipcc", *HIPCC_FLAGS, *extra, "-I" + os.path.join(ROOT, "include"), *srcs, "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
