@@ -182,12 +182,24 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
     const int my_tiles = (ntile_sp - slice + k.slices - 1) / k.slices;
     const int n_iter = my_tiles * nchunk;
 
-    f32x4 reg[NITEM];
-    f32x4 regB[NITEM_B > 0 ? NITEM_B : 1];
-    unsigned valid = 0;            // generic walk: bit i = item i lies inside the image
-    unsigned rowmask = 0;          // row-structured: bit i = core row of pass i inside the image (wave-uniform)
-    unsigned evalid = 0;           //                 bit j = edge item j inside the image
-    bool xok = false;              //                 this thread's core column (and channel quad) exists
+    // Staging register sets.  DEPTH = 1: the halo of iteration i+1 is requested after the commit of iteration i and the
+    // weight fragments at the top of the iteration that consumes them (registers are the scarce resource of the wide-
+    // tile variants: 3 waves per SIMD).  DEPTH = 2 requests halo AND fragments of iteration i+2 as soon as iteration i has
+    // been committed (two iterations to land instead of one MFMA phase).  Built and parity-tested for the small-spatial
+    // CK = 32 variants, which have the registers for it — and measured neutral to slightly slower there (8x8 128->128:
+    // 15.1 -> 15.8 us; those kernels are bound by launch + prologue + epilogue, not by the round trip), so it is off.
+#ifndef CCDM_DEEP_PREFETCH
+#define CCDM_DEEP_PREFETCH 0
+#endif
+    constexpr int DEPTH = (CCDM_DEEP_PREFETCH && PREC != CCDM_PREC_F32 && CKT == 32 && 8 * (NITEM + NITEM_B) <= 136) ? 2 : 1;
+    f32x4 reg[DEPTH][NITEM];
+    f32x4 regB[DEPTH][NITEM_B > 0 ? NITEM_B : 1];
+    unsigned valid[DEPTH];         // generic walk: bit i = item i lies inside the image
+    unsigned rowmask[DEPTH];       // row-structured: bit i = core row of pass i inside the image (wave-uniform)
+    unsigned evalid[DEPTH];        //                 bit j = edge item j inside the image
+    bool xok[DEPTH];               //                 this thread's core column (and channel quad) exists
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) { valid[d] = 0; rowmask[d] = 0; evalid[d] = 0; xok[d] = false; }
 
     // thread -> staging coordinates (row-structured walk): channel quad tq, core column px, row within a pass rip.
     // tq and px are re-derived from an opaque copy of tid inside issue/commit: kept live across the MFMA phase and the
@@ -218,7 +230,8 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
     }
 
     // ---- issue: global -> registers for iteration `it` (tile, chunk) ----
-    auto issue = [&](const int ch, const int ty, const int tx) {
+    auto issue = [&](auto D_, const int ch, const int ty, const int tx) {
+        constexpr int d = decltype(D_)::value;
         const unsigned cc = __builtin_amdgcn_readlane(T_cc, ch);
         const int Cs = cc & 0xffffu, cb = cc >> 16;
         const char* srcb = reinterpret_cast<const char*>(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(T_hi, ch) << 32) |
@@ -238,10 +251,10 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
             const unsigned rowb = (unsigned)aWin * (unsigned)Cs * 4u;            // bytes per source row (uniform)
             {
                 const int ix = ox0 + px;                                           // core columns: halo x = px + PAD
-                xok = cok & (ix < Wc);
+                xok[d] = cok & (ix < Wc);
                 const int ixc = min(ix, Wc - 1);
                 const unsigned colb = ((unsigned)(ixc >> ups) * (unsigned)Cs + cq) << 2;
-                rowmask = 0;
+                rowmask[d] = 0;
 #pragma unroll
                 for (int i = 0; i < NCORE; ++i) {
                     const int row = rip + i * RPP;
@@ -249,12 +262,12 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                     const bool rok = ((unsigned)iy < (unsigned)Hc) & ((i + 1) * RPP <= HHt || row < HHt);
                     const int iyc = min(max(iy, 0), Hc - 1);
                     const unsigned sy = (unsigned)(iyc >> ups);
-                    if constexpr (ROW_UNIFORM) reg[i] = load16_uniform_base(srcb + (size_t)(sy * rowb), colb);
-                    else reg[i] = *reinterpret_cast<const f32x4*>(srcb + (sy * rowb + colb));
-                    rowmask |= (rok ? 1u : 0u) << i;
+                    if constexpr (ROW_UNIFORM) reg[d][i] = load16_uniform_base(srcb + (size_t)(sy * rowb), colb);
+                    else reg[d][i] = *reinterpret_cast<const f32x4*>(srcb + (sy * rowb + colb));
+                    rowmask[d] |= (rok ? 1u : 0u) << i;
                 }
             }
-            evalid = 0;
+            evalid[d] = 0;
 #pragma unroll
             for (int j = 0; j < NEDGE; ++j) {
                 const unsigned e = t_ + j * NT;
@@ -264,11 +277,11 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                 const bool ok = cok & (e < (unsigned)EDGE_ITEMS) & ((unsigned)iy < (unsigned)Hc) & ((unsigned)ix < (unsigned)Wc);
                 const int iyc = min(max(iy, 0), Hc - 1), ixc = min(max(ix, 0), Wc - 1);
                 const unsigned sy = (unsigned)(iyc >> ups), sx = (unsigned)(ixc >> ups);
-                reg[NCORE + j] = *reinterpret_cast<const f32x4*>(srcb + (size_t)(sy * rowb + ((sx * (unsigned)Cs + cq) << 2)));
-                evalid |= (ok ? 1u : 0u) << j;
+                reg[d][NCORE + j] = *reinterpret_cast<const f32x4*>(srcb + (size_t)(sy * rowb + ((sx * (unsigned)Cs + cq) << 2)));
+                evalid[d] |= (ok ? 1u : 0u) << j;
             }
         } else {
-            valid = 0;
+            valid[d] = 0;
             // item = tid + i*NT  ->  halo pixel hp = item / QPP (hy = hp / HWt, hx = hp % HWt), channel quad q = item % QPP.
             // NT % QPP == 0, so q is the same for every i and hp advances by NT/QPP: (hy, hx) are carried incrementally
             // (unsigned, no per-item division).
@@ -286,8 +299,8 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                 const int iyc = min(max(iy, 0), Hc - 1), ixc = min(max(ix, 0), Wc - 1);
                 const int sy = iyc >> ups, sx = ixc >> ups;
                 const unsigned off = ((unsigned)(sy * aWin + sx) * (unsigned)Cs + cq) << 2;      // bytes within the sample
-                reg[i] = *reinterpret_cast<const f32x4*>(srcb + off);
-                valid |= (ok ? 1u : 0u) << i;
+                reg[d][i] = *reinterpret_cast<const f32x4*>(srcb + off);
+                valid[d] |= (ok ? 1u : 0u) << i;
                 hy += DHY; hx += DHX;
                 if (hx >= (unsigned)HWt) { hx -= HWt; hy += 1; }
             }
@@ -296,7 +309,8 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
     // ---- issueB: this chunk's weight fragments, global (L2-resident) -> registers.  Requested at the top of the
     //      iteration that consumes them — their (short) latency hides behind the commit's arithmetic — so that they
     //      do not occupy 4*NITEM_B registers across the MFMA phase and the epilogue like the halo prefetch does.
-    auto issueB = [&](const int ch) {
+    auto issueB = [&](auto D_, const int ch) {
+        constexpr int d = decltype(D_)::value;
         const bool sk = ch >= nchunk_main;
         unsigned t_ = tid;
         asm volatile("" : "+v"(t_));
@@ -315,14 +329,15 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                 const unsigned rem = B_MULTI ? remb : remb + (unsigned)(NT * (i % DB) * 16);
                 ts = ts < nslab ? ts : 0u;
                 const unsigned slab = (ts / KST) * wtap + (ts % KST) * wks;
-                regB[i] = load16_uniform_base(wq + ((size_t)slab << 4), rem);
+                regB[d][i] = load16_uniform_base(wq + ((size_t)slab << 4), rem);
             }
         }
     };
     // ---- commit: registers -> affine -> SiLU -> [fp16 hi|lo split] -> LDS (zero where padded) ----
     // The chunk's transform is uniform (GroupNorm / SiLU apply to the main segment only): one specialised, branch-free
     // body per combination; padding is a select, not a branch.
-    auto commit_body = [&](auto GN_, auto ACT_, int c0) {
+    auto commit_body = [&](auto D_, auto GN_, auto ACT_, int c0) {
+        constexpr int d = decltype(D_)::value;
         constexpr bool GN = decltype(GN_)::value, ACT = decltype(ACT_)::value;
         unsigned t_ = tid;
         asm volatile("" : "+v"(t_));
@@ -372,39 +387,39 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
 #pragma unroll
             for (int i = 0; i < NCORE; ++i)
                 if ((i + 1) * RPP <= HHt || rip + i * RPP < HHt)
-                    put(reg[i], xok & (((rowmask >> i) & 1u) != 0u), hp0 + i * RPP * HWt);
+                    put(reg[d][i], xok[d] & (((rowmask[d] >> i) & 1u) != 0u), hp0 + i * RPP * HWt);
 #pragma unroll
             for (int j = 0; j < NEDGE; ++j) {
                 const unsigned e = t_ + j * NT;
                 if (e < (unsigned)EDGE_ITEMS) {
                     const unsigned side = (e / QPP) % ECOLS, row = e / (ECOLS * QPP);
                     const int hx = side < (unsigned)PAD ? (int)side : TW + (int)side;
-                    put(reg[NCORE + j], ((evalid >> j) & 1u) != 0u, (int)row * HWt + hx);
+                    put(reg[d][NCORE + j], ((evalid[d] >> j) & 1u) != 0u, (int)row * HWt + hx);
                 }
             }
         } else {
 #pragma unroll
             for (int i = 0; i < NITEM; ++i) {
                 const unsigned item = t_ + i * NT;
-                if (item < (unsigned)(HP * QPP)) put(reg[i], ((valid >> i) & 1u) != 0u, (int)(item / QPP));
+                if (item < (unsigned)(HP * QPP)) put(reg[d][i], ((valid[d] >> i) & 1u) != 0u, (int)(item / QPP));
             }
         }
         if (PREC != CCDM_PREC_F32) {
 #pragma unroll
             for (int i = 0; i < NITEM_B; ++i) {
                 const int j = (int)t_ + i * NT;
-                if ((i + 1) * NT <= NB4 || j < NB4) ldsB[j] = regB[i];
+                if ((i + 1) * NT <= NB4 || j < NB4) ldsB[j] = regB[d][i];
             }
         }
     };
-    auto commit = [&](const int ch) {
+    auto commit = [&](auto D_, const int ch) {
         const bool sk = ch >= nchunk_main;
         const int c0 = (sk ? ch - nchunk_main : ch) * CK;
         const bool gn = has_gn && !sk, act = a.act == CCDM_ACT_SILU && !sk;
-        if (gn && act) commit_body(std::true_type{}, std::true_type{}, c0);
-        else if (gn) commit_body(std::true_type{}, std::false_type{}, c0);
-        else if (act) commit_body(std::false_type{}, std::true_type{}, c0);
-        else commit_body(std::false_type{}, std::false_type{}, c0);
+        if (gn && act) commit_body(D_, std::true_type{}, std::true_type{}, c0);
+        else if (gn) commit_body(D_, std::true_type{}, std::false_type{}, c0);
+        else if (act) commit_body(D_, std::false_type{}, std::true_type{}, c0);
+        else commit_body(D_, std::false_type{}, std::false_type{}, c0);
     };
 
     f32x16 acc[MI][NI];
@@ -421,8 +436,19 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
     };
     int chunk = 0, cur_ty = slice / k.tiles_x, cur_tx = slice % k.tiles_x;
     int pf_ch = 0, pf_ty = cur_ty, pf_tx = cur_tx;
-    if (n_iter > 0) { issue(pf_ch, pf_ty, pf_tx); advance(pf_ch, pf_ty, pf_tx); }
-    for (int it = 0; it < n_iter; ++it) {
+    // prologue: fill every register set (sets beyond the last iteration request clamped addresses: harmless, branch-free)
+    if (n_iter > 0) {
+        issue(std::integral_constant<int, 0>{}, pf_ch, pf_ty, pf_tx);
+        if constexpr (DEPTH > 1) issueB(std::integral_constant<int, 0>{}, pf_ch);
+        advance(pf_ch, pf_ty, pf_tx);
+        if constexpr (DEPTH > 1) {
+            issue(std::integral_constant<int, 1>{}, pf_ch, pf_ty, pf_tx);
+            issueB(std::integral_constant<int, 1>{}, pf_ch);
+            advance(pf_ch, pf_ty, pf_tx);
+        }
+    }
+    // one iteration = one (tile, chunk); D_ = the register set it consumes (static: the loop below is unrolled by DEPTH)
+    auto iterate = [&](auto D_) {
         if (chunk == 0) {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
@@ -432,16 +458,20 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                     for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
         }
         CCDM_STAMP(2);
-        if (!CCDM_DBG(4)) issueB(chunk);
+        if constexpr (DEPTH == 1) { if (!CCDM_DBG(4)) issueB(D_, chunk); }
         if (!CCDM_DBG(256)) __syncthreads();          // previous MFMA phase has finished reading LDS (and ab[] is visible)
         CCDM_STAMP(3);
-        if (!CCDM_DBG(2)) commit(chunk);
+        if (!CCDM_DBG(2)) commit(D_, chunk);
         CCDM_STAMP(4);
         if (!CCDM_DBG(256)) __syncthreads();
         CCDM_STAMP(5);
         // next tile-chunk's HBM reads fly during the MFMA phase (after the last iteration this requests a tile past the
         // slice's last one: addresses are clamped into the tensor, the data is never committed — harmless, branch-free)
-        if (!CCDM_DBG(4)) { issue(pf_ch, pf_ty, pf_tx); advance(pf_ch, pf_ty, pf_tx); }
+        if (!CCDM_DBG(4)) {       // refill the set just committed: iteration it + DEPTH
+            issue(D_, pf_ch, pf_ty, pf_tx);
+            if constexpr (DEPTH > 1) issueB(D_, pf_ch);
+            advance(pf_ch, pf_ty, pf_tx);
+        }
 
         CCDM_STAMP(6);
         const bool skc = chunk >= nchunk_main;                   // uniform
@@ -665,6 +695,10 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
             }
         }
         advance(chunk, cur_ty, cur_tx);
+    };
+    for (int it = 0; it < n_iter; it += DEPTH) {
+        iterate(std::integral_constant<int, 0>{});
+        if constexpr (DEPTH > 1) { if (it + 1 < n_iter) iterate(std::integral_constant<int, 1>{}); }
     }
 
     CCDM_STAMP(8);
@@ -766,7 +800,10 @@ static int launch_geo(const ConvK& k, const ConvGeo& g, int NI, int ck, dim3 gri
 template <int PREC>
 static int launch_prec(const ConvK& k, const ConvGeo& g, int NI, int ck, dim3 grid, size_t lds, hipStream_t s) {
 #ifdef CCDM_EXPERIMENT   // compile one instantiation only (register/ISA experiments)
-    hipLaunchKernelGGL((k_conv<CCDM_PREC_F16X3, CCDM_EXPERIMENT_CK, 3, 1, CCDM_EXPERIMENT_GEO>), grid, dim3(256), lds, s, k);
+#ifndef CCDM_EXPERIMENT_THREADS
+#define CCDM_EXPERIMENT_THREADS 256
+#endif
+    hipLaunchKernelGGL((k_conv<CCDM_PREC_F16X3, CCDM_EXPERIMENT_CK, 3, 1, CCDM_EXPERIMENT_GEO>), grid, dim3(CCDM_EXPERIMENT_THREADS), lds, s, k);
     return 0;
 #else
     if (k.a.ksize == 3) return launch_geo<PREC, 3>(k, g, NI, ck, grid, lds, s);
