@@ -26,6 +26,7 @@
 #include "ccdm_conv_common.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <type_traits>
 #include <vector>
 
@@ -188,12 +189,20 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
     // been committed (two iterations to land instead of one MFMA phase).  Built and parity-tested for the small-spatial
     // CK = 32 variants, which have the registers for it — and measured neutral to slightly slower there (8x8 128->128:
     // 15.1 -> 15.8 us; those kernels are bound by launch + prologue + epilogue, not by the round trip), so it is off.
+    //   Wide tiles, one n-tile (the 128x128 / 64x64 stages, HBM-bound): a second HALO set only (+4*NITEM registers, still
+    //   3 waves per SIMD); the fragments stay top-of-iteration.
 #ifndef CCDM_DEEP_PREFETCH
 #define CCDM_DEEP_PREFETCH 0
 #endif
-    constexpr int DEPTH = (CCDM_DEEP_PREFETCH && PREC != CCDM_PREC_F32 && CKT == 32 && 8 * (NITEM + NITEM_B) <= 136) ? 2 : 1;
+#ifndef CCDM_DEEP_HALO
+#define CCDM_DEEP_HALO 0      // measured: 84 -> 94 us on 32->32 @128x128 (more lines in flight per XCD than its L2 holds, twice the loop code)
+#endif
+    constexpr bool DEEP_B = CCDM_DEEP_PREFETCH && PREC != CCDM_PREC_F32 && CKT == 32 && 8 * (NITEM + NITEM_B) <= 136;
+    constexpr bool DEEP_A = CCDM_DEEP_HALO && PREC != CCDM_PREC_F32 && STRIDE == 1 && TW == 32 && NI == 1;
+    constexpr int DEPTH = (DEEP_A || DEEP_B) ? 2 : 1;
+    constexpr int DEPTH_B = DEEP_B ? 2 : 1;
     f32x4 reg[DEPTH][NITEM];
-    f32x4 regB[DEPTH][NITEM_B > 0 ? NITEM_B : 1];
+    f32x4 regB[DEPTH_B][NITEM_B > 0 ? NITEM_B : 1];
     unsigned valid[DEPTH];         // generic walk: bit i = item i lies inside the image
     unsigned rowmask[DEPTH];       // row-structured: bit i = core row of pass i inside the image (wave-uniform)
     unsigned evalid[DEPTH];        //                 bit j = edge item j inside the image
@@ -329,7 +338,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                 const unsigned rem = B_MULTI ? remb : remb + (unsigned)(NT * (i % DB) * 16);
                 ts = ts < nslab ? ts : 0u;
                 const unsigned slab = (ts / KST) * wtap + (ts % KST) * wks;
-                regB[d][i] = load16_uniform_base(wq + ((size_t)slab << 4), rem);
+                regB[DEEP_B ? d : 0][i] = load16_uniform_base(wq + ((size_t)slab << 4), rem);
             }
         }
     };
@@ -408,7 +417,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
 #pragma unroll
             for (int i = 0; i < NITEM_B; ++i) {
                 const int j = (int)t_ + i * NT;
-                if ((i + 1) * NT <= NB4 || j < NB4) ldsB[j] = regB[d][i];
+                if ((i + 1) * NT <= NB4 || j < NB4) ldsB[j] = regB[DEEP_B ? d : 0][i];
             }
         }
     };
@@ -439,11 +448,11 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
     // prologue: fill every register set (sets beyond the last iteration request clamped addresses: harmless, branch-free)
     if (n_iter > 0) {
         issue(std::integral_constant<int, 0>{}, pf_ch, pf_ty, pf_tx);
-        if constexpr (DEPTH > 1) issueB(std::integral_constant<int, 0>{}, pf_ch);
+        if constexpr (DEEP_B) issueB(std::integral_constant<int, 0>{}, pf_ch);
         advance(pf_ch, pf_ty, pf_tx);
         if constexpr (DEPTH > 1) {
             issue(std::integral_constant<int, 1>{}, pf_ch, pf_ty, pf_tx);
-            issueB(std::integral_constant<int, 1>{}, pf_ch);
+            if constexpr (DEEP_B) issueB(std::integral_constant<int, 1>{}, pf_ch);
             advance(pf_ch, pf_ty, pf_tx);
         }
     }
@@ -458,7 +467,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                     for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
         }
         CCDM_STAMP(2);
-        if constexpr (DEPTH == 1) { if (!CCDM_DBG(4)) issueB(D_, chunk); }
+        if constexpr (!DEEP_B) { if (!CCDM_DBG(4)) issueB(D_, chunk); }
         if (!CCDM_DBG(256)) __syncthreads();          // previous MFMA phase has finished reading LDS (and ab[] is visible)
         CCDM_STAMP(3);
         if (!CCDM_DBG(2)) commit(D_, chunk);
@@ -469,7 +478,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
         // slice's last one: addresses are clamped into the tensor, the data is never committed — harmless, branch-free)
         if (!CCDM_DBG(4)) {       // refill the set just committed: iteration it + DEPTH
             issue(D_, pf_ch, pf_ty, pf_tx);
-            if constexpr (DEPTH > 1) issueB(D_, pf_ch);
+            if constexpr (DEEP_B) issueB(D_, pf_ch);
             advance(pf_ch, pf_ty, pf_tx);
         }
 
@@ -817,7 +826,10 @@ int conv_slices(int Hout, int Wout, int stride) {
     // 12 slices for big images: with 3 resident blocks per CU, 64 samples x 12 slices = 768 blocks fill the 256 CUs
     // in exactly one round.  A function of the spatial size only (never of N): sharding the batch must not change
     // the order in which statistics partials are added.
-    if (tiles >= 48) return 12;
+    if (tiles >= 48) {
+        static const int ovr = getenv("CCDM_SLICES") ? atoi(getenv("CCDM_SLICES")) : 0;     // experiment hook
+        return ovr > 0 && ovr <= CCDM_STATS_MAX_SLICES ? ovr : 12;
+    }
     return tiles < CCDM_STATS_MAX_SLICES ? tiles : CCDM_STATS_MAX_SLICES;
 }
 
