@@ -135,7 +135,6 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
     const int dbg = a.prec >> 8;          // ablation switches for tools/bench_conv.py (CCDM_ABLATION builds only)
     (void)dbg;
 
-    if (has_gn) compute_gn_affine(a, n, emb_row, ab);
     const int aWout = a.Wout, aCout = a.Cout, aHout = a.Hout, aWin = a.Win;
     const size_t in_px = (size_t)a.Hin * a.Win;
     const size_t out_px = (size_t)a.Hout * a.Wout;
@@ -456,6 +455,9 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
             advance(pf_ch, pf_ty, pf_tx);
         }
     }
+    // GroupNorm's (scale, shift) table for this sample — after the first halo request is on its way: the statistics loads
+    // and the fp64 finalisation (~1.5 us) then run under that request's round trip instead of in front of it
+    if (has_gn) compute_gn_affine(a, n, emb_row, ab);
     // one iteration = one (tile, chunk); D_ = the register set it consumes (static: the loop below is unrolled by DEPTH)
     auto iterate = [&](auto D_) {
         if (chunk == 0) {
@@ -883,7 +885,14 @@ int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
     // small spatial stages have few pixel tiles: spread the output-channel tiles over blocks instead;
     // wide tiles take at most 2 n-tiles per block (register budget of the staged B chunk)
     if (g.TW < 32) NI = 1;
-    else NI = (k.ntiles % 2 == 0) ? 2 : 1;
+    else {
+        // two n-tiles per block share one staged halo (half the staging work) but need 236 VGPRs and 64 KB of LDS (two blocks
+        // per CU): worth it only when there are blocks to spare.  Measured at the 32x32 stage (64 samples x 4 tiles): one n-tile
+        // per block 25.6 us vs 28.0; at 64x64 outputs (16 tiles per sample) two n-tiles win, 67.8 vs 70.6.  (A partitioning
+        // choice only: every output element is computed by the same instruction sequence either way.)
+        const long blocks2 = (long)a.N * conv_slices(a.Hout, a.Wout, a.stride) * (k.ntiles / 2);
+        NI = (k.ntiles % 2 == 0 && blocks2 >= 512) ? 2 : 1;
+    }
     k.tiles_x = cdiv(a.Wout, g.TW);
     k.tiles_y = cdiv(a.Hout, g.TH);
     k.slices = conv_slices(a.Hout, a.Wout, a.stride);
