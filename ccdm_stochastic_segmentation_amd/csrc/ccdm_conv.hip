@@ -900,6 +900,8 @@ int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
     if (a.out_stats) CCDM_REQUIRE(a.out_slices == k.slices, "conv: out_slices %d != %d", a.out_slices, k.slices);
     const int HP = ((g.TH - 1) * a.stride + a.ksize) * ((g.TW - 1) * a.stride + a.ksize);
     const int ck = chunk_ck(a, g);
+    CCDM_REQUIRE(a.C1 == 0 || a.C0 % ck == 0, "conv: first source has %d channels; a concatenated input must split at a multiple of the %d-channel chunk", a.C0, ck);
+    CCDM_REQUIRE(a.SC1 == 0 || a.SC0 % ck == 0, "conv: first skip source has %d channels; a concatenated input must split at a multiple of the %d-channel chunk", a.SC0, ck);
     CCDM_REQUIRE((k.cin_pad + k.cin_pad_skip) / ck <= 64, "conv: %d input (+%d skip) channels make more than 64 chunks of %d (chunk descriptors live in the 64 lanes of a register)",
                  k.cin_pad, k.cin_pad_skip, ck);
     size_t lds = (size_t)HP * (prec == CCDM_PREC_F32 ? 33 * 4 : ck * 4 + 16);

@@ -67,6 +67,11 @@ CONV_CASES = [
     (32, 0, 32, 20, 36, 3, 1, 0, 1, 1, 1, 1),     # ragged H,W everywhere
     (384, 64, 64, 8, 16, 3, 1, 0, 1, 1, 1, 0),    # DINO-widened block: 448 ch, 14 ch/group
     (160, 0, 160, 8, 8, 1, 1, 0, 0, 0, 0, 0),     # 5 n-tiles -> padded to 8
+    (16, 0, 32, 8, 8, 3, 1, 0, 0, 0, 0, 1),       # 8x8 tile with 16-channel chunks: a wave straddles two staging rows (per-lane row math), tap split
+    (32, 0, 6, 8, 8, 3, 1, 0, 1, 1, 0, 0),        # 8x8 tile, Cout % 4 != 0: no tap split, two edge items per thread, scalar epilogue
+    (32, 0, 32, 10, 12, 3, 1, 1, 1, 1, 1, 0),     # upsample on load with ragged tiles (20x24 output)
+    (32, 0, 64, 20, 36, 1, 1, 0, 1, 0, 0, 1),     # 1x1 on ragged tiles, two n-tiles, residual
+    (48, 16, 32, 12, 20, 3, 1, 0, 0, 1, 0, 0),    # 16-channel chunks across a concat seam, SiLU without GroupNorm
 ]
 
 
@@ -104,6 +109,10 @@ def test_conv(U, case, prec):
         ref = ref + res
     # ---- HIP ----
     srcs = [U.nhwc(xa)] + ([U.nhwc(xb)] if c1 else [])
+    if c1 and prec == hip.PREC_F32 and c0 % 32:      # exact-fp32 chunks are 32 channels wide: the seam must fall on a chunk boundary
+        with pytest.raises(hip.CcdmHipError, match="chunk"):
+            U.conv2d(srcs, w.numpy(), b.numpy(), k, prec=prec, want_stats=False)
+        return
     stats = [U.gn_stats(s, 3 if s.shape[1] * s.shape[2] >= 64 else 1) for s in srcs] if gn else None
     out, ost = U.conv2d(srcs, w.numpy(), b.numpy(), k, stats=stats, gamma=gamma.numpy(), beta=beta.numpy(),
                         act=hip.ACT_SILU if act else hip.ACT_NONE, stride=stride, up=bool(up),
@@ -613,3 +622,12 @@ def test_c3_shaped_t1000_sharded_sampling(U):
     assert torch.equal(part, full[lo:hi])
     pred = full.reshape(B_img, S, 2, 128, 128)          # [B_img, S, K, H, W] as evaluate_lidc_uncertainty.py:103
     assert pred.shape[1] == S
+
+
+@pytest.mark.gpu
+def test_conv_rejects_more_than_64_chunks(U):
+    """The per-chunk operand descriptors live in the 64 lanes of a register: a conv with more chunks must fail loudly."""
+    x = torch.zeros((1, 8, 32, 1040), device=U.DEV)          # 1040 channels / 16 per chunk = 65 chunks at a 32-wide tile
+    w = np.zeros((32, 1040, 3, 3), dtype=np.float32)
+    with pytest.raises(hip.CcdmHipError, match="chunks"):
+        U.conv2d([x], w, np.zeros(32, dtype=np.float32), 3, prec=hip.PREC_F16X3, want_stats=False)
