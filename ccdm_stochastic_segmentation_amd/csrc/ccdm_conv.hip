@@ -589,6 +589,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                 // ---- fast path: accumulators -> wave-private LDS rows [pixel][32 ch] -> float4 per lane
                 //      (8 lanes cover one pixel's 128-byte row: residual loads and stores move 16 B per lane) ----
                 if (!CCDM_DBG(256)) __syncthreads();                 // every wave is done reading the A/B tiles
+                CCDM_STAMP(9);
                 const int cq = lane_ & 7, prow = lane_ >> 3;
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
@@ -635,10 +636,11 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
 #pragma unroll
                             for (int r = 0; r < 16; ++r) {
                                 const int pl = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane_ >> 5);
-                                epi[pl * EPS + (lane_ & 31)] = (PREC == CCDM_PREC_F32 ? acc[mi][ni][r] : acc[mi][ni][r] * wsc) + add;
+                                epi[pl * EPS + (lane_ & 31)] = PREC == CCDM_PREC_F32 ? acc[mi][ni][r] + add : fmaf(acc[mi][ni][r], wsc, add);   // wsc is a power of two: the product is exact, fma == mul + add
                             }
                     }
                     if (KSP > 1) __syncthreads();                  // all row groups' partials are in LDS
+                    CCDM_STAMP(10);
                     const float* epi0 = reinterpret_cast<const float*>(halo_b) + wave * (MI * 32 * EPS);   // row group 0 of this sub-tile
                     {
 #pragma unroll
@@ -673,6 +675,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                     else { if (full) epi_ni(std::true_type{}, std::false_type{}); else epi_ni(std::false_type{}, std::false_type{}); }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { s1[ni][e] += t1[e]; s2[ni][e] += t2[e]; }
+                    CCDM_STAMP(11);
                 }
             } else {
 #pragma unroll
@@ -828,10 +831,10 @@ int conv_slices(int Hout, int Wout, int stride) {
     // 12 slices for big images: with 3 resident blocks per CU, 64 samples x 12 slices = 768 blocks fill the 256 CUs
     // in exactly one round.  A function of the spatial size only (never of N): sharding the batch must not change
     // the order in which statistics partials are added.
-    if (tiles >= 48) {
-        static const int ovr = getenv("CCDM_SLICES") ? atoi(getenv("CCDM_SLICES")) : 0;     // experiment hook
-        return ovr > 0 && ovr <= CCDM_STATS_MAX_SLICES ? ovr : 12;
-    }
+    static const int ovr = getenv("CCDM_SLICES") ? atoi(getenv("CCDM_SLICES")) : 0;     // experiment hook
+    if (ovr > 0 && ovr <= CCDM_STATS_MAX_SLICES && tiles >= ovr) return ovr;
+    if (tiles >= 48) return 12;
+    if (tiles >= 16) return 8;       // 64x64: 8 slices x 2 tiles (512 blocks, all resident) 28.8 us vs 16 x 1 (1024 blocks, a thin second round) 30.7
     return tiles < CCDM_STATS_MAX_SLICES ? tiles : CCDM_STATS_MAX_SLICES;
 }
 
