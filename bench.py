@@ -77,6 +77,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", type=int, default=0, help="1: replay each denoise step as a HIP graph (no kernel taps)")
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH)
+    ap.add_argument("--rng", choices=["philox", "torch_cpu"], default="philox",
+                    help="philox: noise generated in the epilogue kernel (the benchmark); torch_cpu: the parity mode — Exp(1) noise drawn "
+                         "on the host in the reference's order and copied over PCIe (host-RNG bound; reported for DESIGN.md, never the headline)")
     ap.add_argument("--prec", choices=["f32", "f16x3"], default="f16x3",
                     help="conv arithmetic: exact fp32 MFMA, or fp16 hi/lo split x3 MFMA with fp32 accumulate (~2^-22)")
     args = ap.parse_args()
@@ -100,7 +103,7 @@ def main():
     model = model.to(dev).eval()
     from ccdm_stochastic_segmentation_amd import hip
     model.prec = hip.PREC_F32 if args.prec == "f32" else hip.PREC_F16X3
-    model.rng, model.philox_seed, model.use_graph = "philox", 2024, bool(args.graph)
+    model.rng, model.philox_seed, model.use_graph = args.rng, 2024, bool(args.graph)
     model.sample_offset = rank * n                                # Philox counters keyed by global sample index
 
     rng = np.random.default_rng(1234)
@@ -153,7 +156,7 @@ def main():
             "ms_per_denoise_step": ms_dstep, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.prec == "f32" else "f32 (conv products as split fp16 hi/lo x3 on MFMA, fp32 accumulate)", "data": "synthetic",
             "config": {"workload": "C2: LIDCv1-shaped 128x128, 2 classes, T=250 cosine, base-32 U-Net (5.70 M params), "
-                                   f"batch={n} per GPU, device Philox RNG, random-init weights",
+                                   f"batch={n} per GPU, {'device Philox RNG' if args.rng == 'philox' else 'host torch-CPU Exp(1) noise over PCIe (parity mode)'}, random-init weights",
                        "global_batch": n * world, "time_steps": T_STEPS, "parallelism": f"batch-shard x{world}",
                        "launch": "hip-graph" if args.graph else "eager"},
         }
