@@ -30,7 +30,7 @@ def gn_stats(x_nhwc: torch.Tensor, slices: int = 1) -> torch.Tensor:
 
 
 def conv2d(srcs, weight, bias, ksize, *, stats=None, gamma=None, beta=None, act=hip.ACT_NONE, stride=1, up=False,
-           emb=None, emb_rows=None, film=None, resid=None, want_stats=True, prec=hip.PREC_F32, skip=None):
+           emb=None, emb_rows=None, film=None, resid=None, want_stats=True, prec=hip.PREC_F32, skip=None, bench=None):
     """srcs: list of 1-2 NHWC cuda tensors; weight OIHW numpy/torch cpu; stats: list of stats tensors or None.
     emb: [rows, E] cpu tensor added per output channel (row per sample via emb_rows) ; film: (table cpu [rows, 2C]).
     Returns (out NHWC cuda, out_stats or None)."""
@@ -100,6 +100,14 @@ def conv2d(srcs, weight, bias, ksize, *, stats=None, gamma=None, beta=None, act=
         args.out_stats, args.out_slices = ost.data_ptr(), S
     hip.check(lib.ccdm_conv2d(C.byref(args), 0), "conv2d")
     sync()
+    if bench is not None:       # tools/bench_conv.py: {"iters": n} in, {"ms": mean launch time} out
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(bench.get("iters", 20)):
+            lib.ccdm_conv2d(C.byref(args), 0)
+        e1.record()
+        sync()
+        bench["ms"] = e0.elapsed_time(e1) / bench.get("iters", 20)
     del keep
     return out, ost
 

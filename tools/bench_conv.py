@@ -93,6 +93,22 @@ def timeline(prec, shape):
     print(f"timeline total {prev - t0} cycles (100 MHz-ish s_memtime ticks): " + " ".join(out[:64]))
 
 
+def run_fused_skip(prec, c0, c1, cout, H, W):
+    """ResBlock tail: conv3x3(SiLU(GN(h))) + conv1x1([xa|xb]) + residual-free, one launch (tests/hip_util.conv2d does the packing)."""
+    from tests import hip_util as U
+    g = torch.Generator(device="cpu").manual_seed(1)
+    h = torch.randn((N, H, W, cout), generator=g).to(DEV)
+    xa = torch.randn((N, H, W, c0), generator=g).to(DEV)
+    xb = torch.randn((N, H, W, c1), generator=g).to(DEV) if c1 else None
+    w = (torch.randn((cout, cout, 3, 3), generator=g) / np.sqrt(cout * 9)).numpy()
+    ws = (torch.randn((cout, c0 + c1, 1, 1), generator=g) / np.sqrt(c0 + c1)).numpy()
+    st = [U.gn_stats(h, 1)]
+    b = {"iters": 20}
+    U.conv2d([h], w, np.zeros(cout, np.float32), 3, stats=st, gamma=np.ones(cout, np.float32), beta=np.zeros(cout, np.float32),
+             act=hip.ACT_SILU, prec=prec, skip=([xa] + ([xb] if c1 else []), ws, np.zeros(cout, np.float32)), bench=b)
+    return b["ms"]
+
+
 if __name__ == "__main__":
     precs = [hip.PREC_F16X3] if len(sys.argv) < 2 else [int(v) for v in sys.argv[1].split(",")]
     only = int(sys.argv[2]) if len(sys.argv) > 2 else None
@@ -113,3 +129,6 @@ if __name__ == "__main__":
                                         [("-mfma", 1), ("-commit", 2), ("-loads", 4), ("-stores", 8), ("ld+st only", 3), ("st only", 7), ("ld only", 11), ("nothing", 15), ("no-barriers(wrong)", 256), ("2blk/CU", 512), ("1blk/CU", 1024), ("2blk ld+st", 512 | 3), ("1blk ld+st", 1024 | 3)])
             print(f"{sh[0]:2d}x {sh[1]+sh[2]:3d}->{sh[3]:3d} @{sh[4]:3d}x{sh[5]:3d} k{sh[6]} s{sh[7]} up{sh[8]} gn{sh[9]}: {ms*1e3:8.1f} us  {tf:7.1f} TF/s  {gbs:7.0f} GB/s(io){abl}")
         print(f"weighted conv total per denoise step: {total:.3f} ms")
+        if only is None:
+            for cnt, c0, c1, cout, H, W in [(3, 32, 32, 32, 128, 128), (3, 32, 32, 32, 64, 64), (3, 64, 64, 64, 32, 32), (3, 96, 96, 96, 16, 16), (3, 128, 128, 128, 8, 8)]:
+                print(f"{cnt:2d}x {cout:3d}->{cout:3d} +skip1x1 {c0 + c1:3d} @{H:3d}x{W:3d}: {run_fused_skip(prec, c0, c1, cout, H, W) * 1e3:8.1f} us")
