@@ -194,7 +194,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
 #define CCDM_DEEP_PREFETCH 0
 #endif
 #ifndef CCDM_DEEP_HALO
-#define CCDM_DEEP_HALO 0      // measured: 84 -> 94 us on 32->32 @128x128 (more lines in flight per XCD than its L2 holds, twice the loop code)
+#define CCDM_DEEP_HALO 0      // same-box A/B: -1.5 % at 128x128, +4 % at 64x64 (L2 misses of the second half-lines vanish, 236 -> 174 MB fetched, time does not follow)
 #endif
     constexpr bool DEEP_B = CCDM_DEEP_PREFETCH && PREC != CCDM_PREC_F32 && CKT == 32 && 8 * (NITEM + NITEM_B) <= 136;
     constexpr bool DEEP_A = CCDM_DEEP_HALO && PREC != CCDM_PREC_F32 && STRIDE == 1 && TW == 32 && NI == 1;
