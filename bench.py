@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", type=int, default=0, help="1: replay each denoise step as a HIP graph (no kernel taps)")
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH)
+    ap.add_argument("--substreams", type=int, default=1,
+                    help="sample the per-GPU batch as this many contiguous sub-batches on concurrent HIP streams (results are bit-identical)")
     ap.add_argument("--rng", choices=["philox", "torch_cpu"], default="philox",
                     help="philox: noise generated in the epilogue kernel (the benchmark); torch_cpu: the parity mode — Exp(1) noise drawn "
                          "on the host in the reference's order and copied over PCIe (host-RNG bound; reported for DESIGN.md, never the headline)")
@@ -105,6 +107,7 @@ def main():
     model.prec = hip.PREC_F32 if args.prec == "f32" else hip.PREC_F16X3
     model.rng, model.philox_seed, model.use_graph = args.rng, 2024, bool(args.graph)
     model.sample_offset = rank * n                                # Philox counters keyed by global sample index
+    model.substreams = args.substreams
 
     rng = np.random.default_rng(1234)
     image_all = rng.uniform(-1, 1, (max(n, 4), 1, H, W)).astype(np.float32)
@@ -120,7 +123,9 @@ def main():
 
     for _ in range(args.warmup):
         one_pass()
-    eng = model._engine(x, image, None)
+    # the executor of sub-batch 0 (the whole batch when substreams == 1) carries the HIP-event taps
+    n_tap = n // max(1, min(args.substreams, n))
+    eng = model._engine(x[:n_tap], image[:n_tap], None, slot=0)
     dom = next(i for i, nm in enumerate(eng.op_names) if nm == "input_blocks.1.0.in_layers.2")
     taps = not args.graph
     if taps:
@@ -158,7 +163,7 @@ def main():
             "config": {"workload": "C2: LIDCv1-shaped 128x128, 2 classes, T=250 cosine, base-32 U-Net (5.70 M params), "
                                    f"batch={n} per GPU, {'device Philox RNG' if args.rng == 'philox' else 'host torch-CPU Exp(1) noise over PCIe (parity mode)'}, random-init weights",
                        "global_batch": n * world, "time_steps": T_STEPS, "parallelism": f"batch-shard x{world}",
-                       "launch": "hip-graph" if args.graph else "eager"},
+                       "launch": "hip-graph" if args.graph else "eager", "substreams": max(1, min(args.substreams, n))},
         }
         step_bytes = (ALGO_MB_PER_SAMPLE_STEP * n + ALGO_WEIGHTS_MB) * 1e6
         res["roofline_step"] = {"bound": "hbm", "achieved": step_bytes / (ms_dstep * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -167,18 +172,21 @@ def main():
         if taps and kern and kern[0][0] > 0:
             cnt = sum(k[0] for k in kern)
             mean_ms = sum(k[0] * k[1] for k in kern) / cnt
-            b = dominant_kernel_bytes(n)
+            b = dominant_kernel_bytes(n_tap)
             ach = b["total"] / (mean_ms * 1e-3) / 1e9
             traffic = None
             pmc = os.path.join(ROOT, "profiles", "r01_pmc_dominant_kernel.json")
-            if os.path.exists(pmc) and n == PER_GPU_BATCH and args.prec == "f16x3":
+            if os.path.exists(pmc) and args.prec == "f16x3":
                 # HBM bytes per launch of this kernel from the committed rocprofv3 --pmc passes (tools/pmc_conv.sh;
-                # FETCH_SIZE x2 + WRITE_SIZE, KiB, per MI355X_MICROARCH.md) — collected off-line, same shape and batch
-                traffic = json.load(open(pmc)).get("hbm_bytes")
+                # FETCH_SIZE x2 + WRITE_SIZE, KiB, per MI355X_MICROARCH.md) — collected off-line on the same shape at 64
+                # samples per launch; every byte of it is per-sample work, so a launch over n_tap samples moves n_tap/64 of it
+                traffic = json.load(open(pmc)).get("hbm_bytes") * n_tap / PER_GPU_BATCH
             res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                                "traffic": traffic, "kernel": ("ccdm::k_conv<1, 16, 3, 1, 8, 32, 4, 2, 1, 1>" if args.prec == "f16x3" else "ccdm::k_conv<0, 32, 3, 1, 8, 32, 4, 2, 1, 1>")
                                          + " = <PREC,CK,KS,STRIDE,TH,TW,WAVES,MI,NI,KSP>, engine op 1 (" + eng.op_names[dom] + ": conv3x3 32->32 @128x128, GN+SiLU on load)",
                                "avg_launch_ms": mean_ms, "launches_timed": cnt, "algorithmic_bytes_per_launch": b["total"],
+                               "samples_per_launch": n_tap,
+                               "concurrent_streams": max(1, min(args.substreams, n)),
                                "achieved_conv_io_only": (b["conv_io"] + b["weights"]) / (mean_ms * 1e-3) / 1e9}
         else:
             res["roofline"] = None

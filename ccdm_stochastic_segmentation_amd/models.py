@@ -194,6 +194,7 @@ class DenoisingModel(nn.Module):
         self.sample_offset = 0          # global index of sample 0 when the batch is sharded over ranks
         self.noise_slice: Optional[Tuple[int, int]] = None   # (global_batch, first_sample) for torch_cpu sharding
         self.use_graph = False
+        self.substreams = 1             # > 1: the batch is sampled as that many contiguous sub-batches on concurrent HIP streams
         self.prec = hip.PREC_F32
         self._engines: Dict[Any, Tuple[int, SamplerEngine]] = {}
 
@@ -217,13 +218,14 @@ class DenoisingModel(nn.Module):
         return self.forward_denoising(x, condition, feature_condition, cast(int, t.item()), label_ref_logits)
 
     # ------------------------------------------------------------------ engine plumbing
-    def _engine(self, x: Tensor, condition: Tensor, feature_condition: Optional[Tensor]) -> SamplerEngine:
+    def _engine(self, x: Tensor, condition: Tensor, feature_condition: Optional[Tensor], slot: int = 0) -> SamplerEngine:
+        """The step executor for this input geometry (cached).  `slot` tells apart the engines of concurrent sub-batches."""
         N, K, H, W = x.shape
         fshape = tuple(feature_condition.shape[1:]) if feature_condition is not None else None
         if not self.unet.spec.feature_condition_idx:
             fshape = None
         dev = next(self.unet.parameters()).device
-        key = (N, H, W, int(condition.shape[1]), fshape, str(dev), self.prec)
+        key = (N, H, W, int(condition.shape[1]), fshape, str(dev), self.prec, slot)
         hit = self._engines.get(key)
         if hit is not None and hit[0] == self.unet._weights_version:
             return hit[1]
@@ -263,7 +265,6 @@ class DenoisingModel(nn.Module):
             raise AttributeError("'DenoisingModel' object has no attribute 'guidance_scale_weights'")
         T = self.time_steps
         t_values = step_values(T, init_t)
-        eng = self._engine(x, condition, feature_condition)
         N, K, H, W = x.shape
         S = len(t_values)
         vote = self.step_T_sample
@@ -273,7 +274,7 @@ class DenoisingModel(nn.Module):
         for t in t_values:
             a, c = self.diffusion.posterior_coeffs(t)
             coeffs.append((a, c, hip.STEP_SAMPLE if t > 1 else last_mode))
-        noise = None
+        host_noise = None
         if self.rng == "torch_cpu":
             n_draws = sum(1 for t in t_values if t > 1)
             if n_draws:
@@ -281,22 +282,47 @@ class DenoisingModel(nn.Module):
                 host = torch.empty((n_draws, gN, H * W * K), dtype=torch.float32)
                 for j in range(n_draws):        # one [gN*H*W, K] draw per step, like torch.multinomial
                     host[j].view(-1).exponential_(1)
-                noise = host[:, first:first + N].contiguous().to(eng.device)
+                host_noise = host[:, first:first + N]
         elif self.rng != "philox":
             raise ValueError(f"unknown rng mode {self.rng!r}")
-        with eng.enter():
-            eng.set_inputs(self._to_index(x, eng.device), condition.to(eng.device), feature_condition)
-            eng.set_tables([float(t) for t in t_values], coeffs)
-            eng.run(S, noise=noise, philox_seed=self.philox_seed, sample_offset=self.sample_offset,
-                    use_graph=self.use_graph)
-            if t_values[-1] > 1 or last_mode == hip.STEP_LAST_KEEP:
-                idx = eng.xt.reshape(N, H, W).long()
-                out = torch.nn.functional.one_hot(idx, K).permute(0, 3, 1, 2).to(torch.float32)
-            elif last_mode == hip.STEP_LAST_CONFIDENCE:
-                out = eng.out_probs.clone().permute(0, 3, 1, 2)          # BCHW view of channels-last memory, like the reference
-            else:
-                out = eng.out_onehot.clone().permute(0, 3, 1, 2)
-        eng.leave()
+        # Samples are independent through all T steps: the batch may be walked as several contiguous
+        # sub-batches, each with its own step executor on its own HIP stream.  The kernels of the low-resolution stages
+        # fill a fraction of the GPU; two sub-batches half a step apart fill each other's gaps.  Nothing a sample sees
+        # depends on the split (statistics are per sample, slices are a function of the spatial size only, noise is keyed
+        # by the global sample index or sliced from the full-batch host draw): the results are bit-identical.
+        nsub = max(1, min(int(self.substreams), N))
+        bounds = [(N * j) // nsub for j in range(nsub + 1)]
+        parts = []
+        for j in range(nsub):
+            lo, hi = bounds[j], bounds[j + 1]
+            fc = feature_condition[lo:hi] if feature_condition is not None else None
+            eng = self._engine(x[lo:hi], condition[lo:hi], fc, slot=j)
+            noise = host_noise[:, lo:hi].contiguous().to(eng.device) if host_noise is not None else None
+            with eng.enter():
+                eng.set_inputs(self._to_index(x[lo:hi], eng.device), condition[lo:hi].to(eng.device), fc)
+                eng.set_tables([float(t) for t in t_values], coeffs)
+            parts.append((eng, noise, lo, hi))
+        if nsub == 1:
+            eng, noise, lo, hi = parts[0]
+            eng.run(S, noise=noise, philox_seed=self.philox_seed, sample_offset=self.sample_offset, use_graph=self.use_graph)
+        else:
+            for s in range(S):                   # one step of every sub-batch in turn: the streams advance side by side
+                for eng, noise, lo, hi in parts:
+                    eng.run(1, first_row=s, noise=noise, philox_seed=self.philox_seed, sample_offset=self.sample_offset + lo,
+                            use_graph=self.use_graph)
+        outs = []
+        for eng, noise, lo, hi in parts:
+            with eng.enter():
+                if t_values[-1] > 1 or last_mode == hip.STEP_LAST_KEEP:
+                    idx = eng.xt.reshape(hi - lo, H, W).long()
+                    out = torch.nn.functional.one_hot(idx, K).permute(0, 3, 1, 2).to(torch.float32)
+                elif last_mode == hip.STEP_LAST_CONFIDENCE:
+                    out = eng.out_probs.clone().permute(0, 3, 1, 2)          # BCHW view of channels-last memory, like the reference
+                else:
+                    out = eng.out_onehot.clone().permute(0, 3, 1, 2)
+            eng.leave()
+            outs.append(out)
+        out = outs[0] if nsub == 1 else torch.cat(outs, 0)
         if out.device != x.device:
             out = out.to(x.device)
         return {"diffusion_out": out}

@@ -631,3 +631,27 @@ def test_conv_rejects_more_than_64_chunks(U):
     w = np.zeros((32, 1040, 3, 3), dtype=np.float32)
     with pytest.raises(hip.CcdmHipError, match="chunks"):
         U.conv2d([x], w, np.zeros(32, dtype=np.float32), 3, prec=hip.PREC_F16X3, want_stats=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rng_mode", ["philox", "torch_cpu"])
+def test_substreams_do_not_change_the_samples(U, rng_mode):
+    """DenoisingModel.substreams: the batch walked as 3 ragged sub-batches on concurrent streams gives bit-identical samples."""
+    from ccdm_stochastic_segmentation_amd.models import build_model
+    from ccdm_stochastic_segmentation_amd.unet_spec import make_synthetic_state_dict
+    bp = dict(base_channels=32, channel_mult=(1, 2), attention_resolutions=[2], num_heads=1, num_head_channels=32,
+              softmax_output=True)
+    T, K, H, W, N = 6, 3, 32, 32, 7
+    model = build_model(T, "cosine", {"s": 0.008}, [(1, H, W), (K, H, W)], (1, H, W), "unet_openai", bp, "datasets.lidc", "confidence", None)
+    model.unet.load_state_dict({k: torch.from_numpy(v) for k, v in make_synthetic_state_dict(model.unet.spec, 3).items()}, strict=True)
+    model = model.to(U.DEV).eval()
+    model.prec, model.rng, model.philox_seed = hip.PREC_F16X3, rng_mode, 99
+    g = np.random.default_rng(5)
+    img = torch.from_numpy(g.uniform(-1, 1, (N, 1, H, W)).astype(np.float32)).to(U.DEV)
+    x = torch.nn.functional.one_hot(torch.from_numpy(g.integers(0, K, (N, H, W))), K).permute(0, 3, 1, 2).float().to(U.DEV)
+    outs = []
+    for sub in (1, 3):
+        model.substreams = sub
+        torch.manual_seed(11)
+        outs.append(model(x, img)["diffusion_out"].cpu())
+    assert torch.equal(outs[0], outs[1])
