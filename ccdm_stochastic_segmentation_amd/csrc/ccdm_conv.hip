@@ -8,13 +8,15 @@
 //   it from LDS: each input element is fetched from HBM once per tile, transformed once, used k*k*Cout times.
 //
 //   Pipeline per block (one (sample, slice) pair, looping over that slice's tiles x channel chunks):
-//       issue(i+1): global -> registers      (raw fp32, in flight during the MFMA phase of step i)
-//       barrier ; commit(i): registers -> GN affine -> SiLU -> [fp16 hi|lo split] -> LDS ; barrier
+//       issueB(i): weight fragments of chunk i, global (L2) -> registers
+//       barrier ; commit(i): halo registers -> GN affine -> SiLU -> [fp16 hi|lo split] -> LDS, fragment registers -> LDS ; barrier
+//       issue(i+1): next halo, global -> registers   (raw fp32, in flight during the MFMA phase of step i)
 //       MFMA phase(i): A and B fragments from LDS only — no vector-memory op between issue and the next
-//       commit, so the prefetch is never dragged in early by the in-order vmcnt queue.  (F16X3; the exact
-//       F32 path reads its pre-packed B fragments straight from L2.)
-//   HBM latency is paid once per tile-chunk and hidden behind the matrix phase; every geometry constant
-//   (halo width, item counts, tap offsets) is compile-time.
+//       commit, so the prefetch is never dragged in early by the in-order vmcnt queue; the LDS reads of tap t+1 are
+//       issued ahead of the MFMAs of tap t.  (F16X3; the exact F32 path reads its pre-packed B fragments straight from L2.)
+//       epilogue on a tile's last chunk: accumulators -> LDS transpose -> (+bias +emb +residual) -> float4 stores, statistics
+//   Every geometry constant (halo width, item counts, tap offsets) is compile-time; the (tile, chunk) walk and each chunk's
+//   operand pointers are scalar state (counters, register-lane descriptors), so the loop carries almost no address arithmetic.
 //
 //   A block leaves its per-channel (sum, sum^2) partials for the *next* GroupNorm in a fixed slot —
 //   no atomics, fixed order, run-to-run deterministic, independent of the batch size.
