@@ -69,7 +69,7 @@ template <int PREC, int CKT> struct Lds {
 // per CU the LDS footprint (A tile 27 KB + B chunk 18 KB) admits
 constexpr int min_waves(int mi, int ni, int prec, int ckt, int threads) {
     if (threads > 512) return 3;                           // 12-wave blocks (tap-split 8x16 tiles): 3 waves per SIMD
-    if (prec != CCDM_PREC_F32 && ckt == 32) return 2;      // small-spatial variant: few blocks per CU anyway, take the registers
+    if (prec != CCDM_PREC_F32 && ckt >= 32) return 2;      // small-spatial variants: few blocks per CU anyway, take the registers
     return mi * ni <= 2 ? 3 : (mi * ni <= 4 ? 2 : 1);
 }
 
@@ -771,12 +771,19 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
 
 // ---------------------------------------------------------------------------------------------------
 // chunk width of the F16X3 path: 32 channels for the small-spatial geometries when the channel counts allow it
+static bool tap_split(const ccdm_conv_args& a, const ConvGeo& g);
 static int chunk_ck(const ccdm_conv_args& a, const ConvGeo& g) {
     if ((a.prec & 255) == CCDM_PREC_F32) return 32;
     const int C = a.C0 + a.C1, SC = a.SC0 + a.SC1;
     const bool ok32 = g.TW < 32 && a.stride == 1 && C % 32 == 0 && (a.C1 == 0 || a.C0 % 32 == 0) &&
                       (!a.skip0 || (SC % 32 == 0 && (a.SC1 == 0 || a.SC0 % 32 == 0)));
-    return ok32 ? 32 : 16;
+    // 8x8 images: 64 channels per chunk — the kernel there is one round of single-tile blocks whose time is the length of
+    // their chain, and every chunk is a barrier-separated round trip; the whole chunk still fits (A 27 KB + B 74 KB for 3x3)
+    const bool ok64 = ok32 && g.TW == 8 && C % 64 == 0 && (a.C1 == 0 || a.C0 % 64 == 0) &&
+                      (!a.skip0 || (SC % 64 == 0 && (a.SC1 == 0 || a.SC0 % 64 == 0))) &&
+                      (a.ksize == 1 || tap_split(a, g));
+    static const int no64 = getenv("CCDM_NO_CK64") ? atoi(getenv("CCDM_NO_CK64")) : 0;     // A/B hook
+    return ok64 && !no64 ? 64 : (ok32 ? 32 : 16);
 }
 
 static bool tap_split(const ccdm_conv_args& a, const ConvGeo& g) {
@@ -787,7 +794,7 @@ static bool tap_split(const ccdm_conv_args& a, const ConvGeo& g) {
 template <int PREC, int CKT, int KS, int STRIDE, int TH, int TW, int WAVES, int MI>
 static int launch_ni(const ConvK& k, int NI, dim3 grid, size_t lds, hipStream_t s) {
     dim3 block(WAVES * 64);
-    if constexpr (TW < 32 || (CKT == 32 && PREC != CCDM_PREC_F32)) {       // narrow tiles always run one n-tile per block (launch_conv)
+    if constexpr (TW < 32 || (CKT >= 32 && PREC != CCDM_PREC_F32)) {       // narrow tiles always run one n-tile per block (launch_conv)
         hipLaunchKernelGGL((k_conv<PREC, CKT, KS, STRIDE, TH, TW, WAVES, MI, 1>), grid, block, lds, s, k);
     } else {
         switch (NI) {
@@ -806,9 +813,13 @@ static int launch_geo(const ConvK& k, const ConvGeo& g, int NI, int ck, dim3 gri
     if (g.TW == 32) return launch_ni<PREC, CK0, KS, 1, 8, 32, 4, 2>(k, NI, grid, lds, s);
     if (PREC != CCDM_PREC_F32 && KS == 3 && tap_split(k.a, g)) {       // small-spatial 3x3: kernel rows split over 3 wave groups
         constexpr int KSPL = KS == 3 ? 3 : 1;
-        if (ck == 32) hipLaunchKernelGGL((k_conv<PREC, 32, KS, 1, 8, 8, 2, 1, 1, KSPL>), grid, dim3(2 * KSPL * 64), lds, s, k);
+        if (ck == 64) hipLaunchKernelGGL((k_conv<PREC, 64, KS, 1, 8, 8, 2, 1, 1, KSPL>), grid, dim3(2 * KSPL * 64), lds, s, k);
+        else if (ck == 32) hipLaunchKernelGGL((k_conv<PREC, 32, KS, 1, 8, 8, 2, 1, 1, KSPL>), grid, dim3(2 * KSPL * 64), lds, s, k);
         else hipLaunchKernelGGL((k_conv<PREC, CK0, KS, 1, 8, 8, 2, 1, 1, KSPL>), grid, dim3(2 * KSPL * 64), lds, s, k);
         return 0;
+    }
+    if (PREC != CCDM_PREC_F32 && ck == 64) {
+        if constexpr (KS == 1) return launch_ni<PREC, 64, KS, 1, 8, 8, 2, 1>(k, NI, grid, lds, s);
     }
     if (PREC != CCDM_PREC_F32 && ck == 32) {
         if (g.TW == 16) return launch_ni<PREC, 32, KS, 1, 8, 16, 4, 1>(k, NI, grid, lds, s);
