@@ -809,7 +809,10 @@ static int launch_ni(const ConvK& k, int NI, dim3 grid, size_t lds, hipStream_t 
 template <int PREC, int KS>
 static int launch_geo(const ConvK& k, const ConvGeo& g, int NI, int ck, dim3 grid, size_t lds, hipStream_t s) {
     constexpr int CK0 = PREC == CCDM_PREC_F32 ? 32 : 16;
-    if (k.a.stride == 2) return launch_ni<PREC, CK0, KS, 2, 8, 8, 2, 1>(k, NI, grid, lds, s);
+    if (k.a.stride == 2) {
+        if constexpr (KS == 3) { if (g.TW == 16) return launch_ni<PREC, CK0, KS, 2, 8, 16, 4, 1>(k, NI, grid, lds, s); }
+        return launch_ni<PREC, CK0, KS, 2, 8, 8, 2, 1>(k, NI, grid, lds, s);
+    }
     if (g.TW == 32) return launch_ni<PREC, CK0, KS, 1, 8, 32, 4, 2>(k, NI, grid, lds, s);
     if (PREC != CCDM_PREC_F32 && KS == 3 && tap_split(k.a, g)) {       // small-spatial 3x3: kernel rows split over 3 wave groups
         constexpr int KSPL = KS == 3 ? 3 : 1;
