@@ -139,6 +139,79 @@ class DiffusionModel(nn.Module):
             return 0.0, 1.0
         return float(self.alphas[i]), float(self.cumalphas[i - 1])
 
+    # ------------------------------------------------------------------ training-time forward pieces
+    # Same names, arguments and results as the reference's methods (diffusion_denoising.py:72-129); the arithmetic runs in
+    # the HIP kernels behind ccdm_mix_uniform / ccdm_theta_post (device tensors only: there is no CPU path).
+    @staticmethod
+    def _dev(x: Tensor, what: str) -> Tensor:
+        if not x.is_cuda:
+            raise hip.CcdmHipError(f"{what}: tensors must live on the GPU (the HIP kernels are the only implementation)")
+        return x.contiguous().float()
+
+    def _per_sample(self, table: Tensor, t: Tensor, N: int, device) -> Tensor:
+        v = table.to(device)[(t.to(device).long() - 1).reshape(-1)].float()
+        return (v.expand(N) if v.numel() == 1 else v).contiguous()
+
+    def _coeffs(self, t: Tensor, N: int, device) -> Tuple[Tensor, Tensor]:
+        """(alpha_t, cumalpha_{t-1}) per sample with the t == 1 override (:91-94, :110-113)."""
+        i = (t.to(device).long() - 1).reshape(-1)
+        a = self.alphas.to(device)[i].clone().float()
+        c = self.cumalphas.to(device)[i - 1].clone().float()
+        a[i == 0] = 0.0
+        c[i == 0] = 1.0
+        if a.numel() == 1:
+            a, c = a.expand(N), c.expand(N)
+        return a.contiguous(), c.contiguous()
+
+    def _mix(self, x: Tensor, s: Tensor) -> Tensor:
+        x = self._dev(x, "q_xt")
+        N, K, H, W = x.shape
+        out = torch.empty_like(x)
+        lib = hip.load()
+        hip.check(lib.ccdm_mix_uniform(x.data_ptr(), s.data_ptr(), N, K, H * W, out.data_ptr(),
+                                       torch.cuda.current_stream(x.device).cuda_stream), "mix_uniform")
+        return out
+
+    def q_xt_given_xtm1(self, xtm1: Tensor, t: Tensor) -> OneHotCategoricalBCHW:
+        """(1 - beta_t) * x_{t-1} + beta_t / K   (:72-78)"""
+        s = 1.0 - self._per_sample(self.betas, t, xtm1.shape[0], xtm1.device)
+        return OneHotCategoricalBCHW(self._mix(xtm1, s.contiguous()))
+
+    def q_xt_given_x0(self, x0: Tensor, t: Tensor) -> OneHotCategoricalBCHW:
+        """cumalpha_t * x_0 + (1 - cumalpha_t) / K   (:80-86)"""
+        return OneHotCategoricalBCHW(self._mix(x0, self._per_sample(self.cumalphas, t, x0.shape[0], x0.device)))
+
+    def _theta(self, xt: Tensor, other: Tensor, t: Tensor, prob_mode: int) -> Tensor:
+        xt, other = self._dev(xt, "theta_post"), self._dev(other, "theta_post")
+        N, K, H, W = xt.shape
+        if other.shape != xt.shape:
+            raise ValueError(f"theta_post: shapes differ {tuple(xt.shape)} vs {tuple(other.shape)}")
+        a, c = self._coeffs(t, N, xt.device)
+        out = torch.empty_like(xt)
+        lib = hip.load()
+        hip.check(lib.ccdm_theta_post(xt.data_ptr(), other.data_ptr(), a.data_ptr(), c.data_ptr(), N, K, H * W, prob_mode,
+                                      out.data_ptr(), torch.cuda.current_stream(xt.device).cuda_stream), "theta_post")
+        return out
+
+    def theta_post(self, xt: Tensor, x0: Tensor, t: Tensor) -> Tensor:
+        """q(x_{t-1} | x_t, x_0)   (:88-97)"""
+        return self._theta(xt, x0, t, 0)
+
+    def theta_post_prob(self, xt: Tensor, theta_x0: Tensor, t: Tensor) -> Tensor:
+        """sum over x_0 of q(x_{t-1} | x_t, x_0) * theta_x0   (:99-129), O(K) per pixel"""
+        return self._theta(xt, theta_x0, t, 1)
+
+    def kl_clamped(self, prob_true: Tensor, prob_pred: Tensor, floor: float = 1e-12) -> Tensor:
+        """The diffusion term of the reference's train_step (trainer.py:266-270):
+        kl_div(log(clamp(prob_pred, min=floor)), prob_true, reduction='none')."""
+        p, q = self._dev(prob_true, "kl_clamped"), self._dev(prob_pred, "kl_clamped")
+        if p.shape != q.shape:
+            raise ValueError(f"kl_clamped: shapes differ {tuple(p.shape)} vs {tuple(q.shape)}")
+        out = torch.empty_like(p)
+        hip.check(hip.load().ccdm_kl_clamped(p.data_ptr(), q.data_ptr(), p.numel(), float(floor), out.data_ptr(),
+                                             torch.cuda.current_stream(p.device).cuda_stream), "kl_clamped")
+        return out
+
 
 class UNetModel(nn.Module):
     """Parameter container with the reference network's exact state_dict layout (398 tensors for the LIDC

@@ -157,6 +157,24 @@ int ccdm_posterior_sample(const ccdm_post_args* a, void* stream);
 int ccdm_pairwise_class_counts(const uint8_t* a /*dev [B,S,HW]*/, const uint8_t* b /*dev [B,L,HW]*/, int B, int S, int L,
                                int HW, int K, int32_t* out /*dev [B,S,L,K,2]*/, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Training-time forward pieces of the categorical diffusion, BCHW fp32 like the reference's
+ * tensors, per-sample coefficients (the host resolves t -> alpha_t / cumalpha_{t-1} incl. the t == 1 override).
+ *   ccdm_mix_uniform : out = s[n]*x + (1-s[n])/K.   With s = 1-beta_t it is the probability table of
+ *                      DiffusionModel.q_xt_given_xtm1 (diffusion_denoising.py:72-78), with s = cumalpha_t of
+ *                      q_xt_given_x0 (:80-86).
+ *   ccdm_theta_post  : prob_mode 0: DiffusionModel.theta_post (:88-97)  q(x_{t-1} | x_t, x_0), both inputs any float
+ *                      tensors (one-hot in the reference's use); prob_mode 1: theta_post_prob (:99-129), the second
+ *                      input a distribution over x_0 — O(K) closed form of the reference's [B,K,K,H,W] product.
+ *   ccdm_kl_clamped  : p*(log p - log max(q, floor)), 0 where p == 0: the diffusion term of Trainer.train_step
+ *                      (trainer.py:266-270, kl_div(log(clamp(q, 1e-12)), p, reduction='none')).
+ * K in [2, 32].  a, c, s: dev [N] fp32.
+ * ------------------------------------------------------------------------------------------------- */
+int ccdm_mix_uniform(const float* x /*dev [N,K,HW]*/, const float* s, int N, int K, int HW, float* out, void* stream);
+int ccdm_theta_post(const float* xt /*dev [N,K,HW]*/, const float* x0 /*dev [N,K,HW]*/, const float* a, const float* c,
+                    int N, int K, int HW, int prob_mode, float* out /*dev [N,K,HW]*/, void* stream);
+int ccdm_kl_clamped(const float* p, const float* q, size_t n, float floor, float* out, void* stream);
+
 /* debugging aid: phase timestamps (s_memtime) one block of the last conv launched with ablation bit 16 recorded */
 int ccdm_debug_read_timeline(unsigned long long* host, int n);
 

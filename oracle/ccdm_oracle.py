@@ -288,6 +288,55 @@ def theta_post_prob(xt: Tensor, theta_x0: Tensor, a: float, c: float) -> Tensor:
 
 
 # ----------------------------------------------------------------------------------------------
+# Training-time forward pieces: per-sample t, any float xt / x0
+#   diffusion_denoising.py:72-129, trainer.py:257-270
+# ----------------------------------------------------------------------------------------------
+def per_sample_coeffs(alphas: Tensor, cumalphas: Tensor, t: Tensor):
+    """(alpha_t, cumalpha_{t-1}) per sample with the t == 1 override (:91-94, :111-113), as fp32 [N] tensors."""
+    i = t.long() - 1
+    a = alphas[i].clone().float()
+    c = cumalphas[i - 1].clone().float()        # i == 0 wraps to the last entry, overwritten below — as in the reference
+    a[i == 0] = 0.0
+    c[i == 0] = 1.0
+    return a, c
+
+
+def q_probs(x: Tensor, s: Tensor) -> Tensor:
+    """s*x + (1-s)/K per sample: q(x_t | x_{t-1}) with s = 1 - beta_t (:72-78), q(x_t | x_0) with s = cumalpha_t (:80-86)."""
+    K = x.shape[1]
+    s = s.float()[:, None, None, None]
+    return s * x + (1 - s) / K
+
+
+def theta_post_t(xt: Tensor, x0: Tensor, a: Tensor, c: Tensor) -> Tensor:
+    """theta_post (:88-97): ((a*xt + (1-a)/K) * (c*x0 + (1-c)/K)) normalised over the class axis."""
+    K = xt.shape[1]
+    a = a[:, None, None, None]
+    c = c[:, None, None, None]
+    theta = (a * xt + (1 - a) / K) * (c * x0 + (1 - c) / K)
+    return theta / theta.sum(dim=1, keepdim=True)
+
+
+def theta_post_prob_t(xt: Tensor, theta_x0: Tensor, a: Tensor, c: Tensor) -> Tensor:
+    """theta_post_prob (:99-129) with per-sample coefficients, O(K) closed form (same algebra as theta_post_prob above):
+        A_k = a*xt_k + (1-a)/K ; b = (1-c)/K ; S = sum_k A_k ; r_d = theta_d / (c*A_d + b*S) ; out_k = A_k * (c*r_k + b*sum_d r_d)"""
+    K = xt.shape[1]
+    a = a[:, None, None, None]
+    c = c[:, None, None, None]
+    A = a * xt + (1 - a) / K
+    b = (1 - c) / K
+    S = A.sum(dim=1, keepdim=True)
+    r = theta_x0 / (c * A + b * S)
+    return A * (c * r + b * r.sum(dim=1, keepdim=True))
+
+
+def kl_clamped(p_true: Tensor, q_pred: Tensor, floor: float = 1e-12) -> Tensor:
+    """The diffusion loss term of Trainer.train_step (trainer.py:266-270): kl_div(log(clamp(q, floor)), p, 'none')
+    = p * (log p - log max(q, floor)), 0 where p == 0."""
+    return torch.nn.functional.kl_div(torch.log(torch.clamp(q_pred, min=floor)), p_true, reduction="none")
+
+
+# ----------------------------------------------------------------------------------------------
 # A6 / T2  categorical draw                   ddpm/models/one_hot_categorical.py:10-54
 # ----------------------------------------------------------------------------------------------
 def ordered_sum_lastdim(p: Tensor) -> Tensor:

@@ -655,3 +655,59 @@ def test_substreams_do_not_change_the_samples(U, rng_mode):
         torch.manual_seed(11)
         outs.append(model(x, img)["diffusion_out"].cpu())
     assert torch.equal(outs[0], outs[1])
+
+
+# ------------------------------------------------------------------------------------------ training-time forward pieces (N3)
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_training_forward_pieces_golden(U, golden, tag):
+    """DiffusionModel.q_xt_given_x0 / q_xt_given_xtm1 / theta_post / theta_post_prob / kl_clamped through the C ABI against the
+    reference's own outputs (per-sample t incl. t == 1 and t == T; one-hot and soft x_t)."""
+    from ccdm_stochastic_segmentation_amd.models import DiffusionModel
+    g = golden["g11_training_forward"]
+    T, K, N, H, W = (int(v) for v in g[f"{tag}_cfg"])
+    sched = str(g[f"{tag}_sched"])
+    dm = DiffusionModel(sched, T, K, schedule_params={"s": 0.008} if sched == "cosine" else None).to(U.DEV)
+    dev = lambda k: torch.from_numpy(g[f"{tag}_{k}"]).to(U.DEV)
+    t, x0, xt, th = dev("t"), dev("x0"), dev("xt"), dev("theta")
+    got = {
+        "q_xt_given_x0": dm.q_xt_given_x0(x0, t).probs,
+        "q_xt_given_xtm1": dm.q_xt_given_xtm1(x0, t).probs,
+        "theta_post": dm.theta_post(xt, x0, t),
+        "theta_post_prob": dm.theta_post_prob(xt, th, t),
+        "theta_post_prob_soft": dm.theta_post_prob(th.roll(1, 0), th, t),
+        "kl": dm.kl_clamped(dev("theta_post"), dev("theta_post_prob")),
+    }
+    for name, v in got.items():
+        np.testing.assert_allclose(v.cpu().numpy(), g[f"{tag}_{name}"], rtol=0, atol=1e-6, err_msg=name)
+    with pytest.raises(hip.CcdmHipError, match="GPU"):
+        dm.theta_post(xt.cpu(), x0.cpu(), t.cpu())
+
+
+@pytest.mark.gpu
+def test_training_forward_pieces_full_size(U):
+    """LIDC-sized batch (N=64, K=2, 128x128) and a K=19 Cityscapes-like case against the oracle; theta_post rows sum to 1;
+    a scalar t broadcasts over the batch like the reference's indexing does."""
+    from ccdm_stochastic_segmentation_amd.models import DiffusionModel
+    for (N, K, H, W, T) in [(64, 2, 128, 128, 250), (3, 19, 64, 96, 1000)]:
+        dm = DiffusionModel("cosine", T, K, schedule_params={"s": 0.008}).to(U.DEV)
+        g = torch.Generator().manual_seed(K)
+        t = torch.randint(1, T + 1, (N,), generator=g)
+        t[0] = 1
+        x0 = torch.nn.functional.one_hot(torch.randint(0, K, (N, H, W), generator=g), K).permute(0, 3, 1, 2).float()
+        xt = torch.nn.functional.one_hot(torch.randint(0, K, (N, H, W), generator=g), K).permute(0, 3, 1, 2).float()
+        th = torch.softmax(torch.randn((N, K, H, W), generator=g), 1)
+        a, c = O.per_sample_coeffs(dm.alphas.cpu(), dm.cumalphas.cpu(), t)
+        tp = dm.theta_post(xt.to(U.DEV), x0.to(U.DEV), t.to(U.DEV))
+        tpp = dm.theta_post_prob(xt.to(U.DEV), th.to(U.DEV), t.to(U.DEV))
+        np.testing.assert_allclose(tp.cpu().numpy(), O.theta_post_t(xt, x0, a, c).numpy(), rtol=0, atol=1e-6)
+        np.testing.assert_allclose(tpp.cpu().numpy(), O.theta_post_prob_t(xt, th, a, c).numpy(), rtol=0, atol=1e-6)
+        np.testing.assert_allclose(tp.sum(1).cpu().numpy(), 1.0, rtol=0, atol=1e-6)
+        np.testing.assert_allclose(tpp.sum(1).cpu().numpy(), 1.0, rtol=0, atol=2e-6)
+        kl = dm.kl_clamped(tp, tpp)
+        np.testing.assert_allclose(kl.cpu().numpy(), O.kl_clamped(tp.cpu(), tpp.cpu()).numpy(), rtol=0, atol=1e-6)
+        q = dm.q_xt_given_x0(x0.to(U.DEV), torch.tensor(7))          # scalar t
+        np.testing.assert_allclose(q.probs.cpu().numpy(), O.q_probs(x0, dm.cumalphas.cpu()[torch.full((N,), 6)]).permute(0, 2, 3, 1).numpy(),
+                                   rtol=0, atol=1e-6)
+        xs = q.sample()
+        assert xs.shape == x0.shape and torch.all(xs.sum(1) == 1)

@@ -237,3 +237,30 @@ def test_g10_lidc_metrics(golden, tag):
     lcm = np.lcm(smp.shape[1], lab.shape[1])
     hm = O.metrics_hungarian_iou(np.repeat(lab, lcm // lab.shape[1], 1), np.repeat(smp, lcm // smp.shape[1], 1), K)
     assert np.array_equal(np.array(hm), g[f"{tag}_hm_iou"])
+
+
+# ------------------------------------------------------------------------------------------ training-time forward pieces (N3)
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_training_forward_pieces_match_reference(golden, tag):
+    """q(x_t|x_0), q(x_t|x_{t-1}), theta_post, theta_post_prob (one-hot and soft x_t) and the clamped KL of train_step,
+    per-sample t incl. t == 1 and t == T, against outputs of the reference itself (tools/gen_goldens_training.py)."""
+    g = golden["g11_training_forward"]
+    T, K, N, H, W = (int(v) for v in g[f"{tag}_cfg"])
+    al, cu = torch.from_numpy(g[f"{tag}_alphas"]), torch.from_numpy(g[f"{tag}_cumalphas"])
+    sched = O.make_schedule(str(g[f"{tag}_sched"]), T, {"s": 0.008} if str(g[f"{tag}_sched"]) == "cosine" else None)
+    np.testing.assert_array_equal(sched[1].numpy(), al.numpy())
+    np.testing.assert_array_equal(sched[2].numpy(), cu.numpy())
+    t = torch.from_numpy(g[f"{tag}_t"])
+    x0, xt, th = (torch.from_numpy(g[f"{tag}_{k}"]) for k in ("x0", "xt", "theta"))
+    a, c = O.per_sample_coeffs(al, cu, t)
+    assert float(a[0]) == 0.0 and float(c[0]) == 1.0          # t[0] == 1
+    got = {
+        "q_xt_given_x0": O.q_probs(x0, cu[t - 1]).permute(0, 2, 3, 1),
+        "q_xt_given_xtm1": O.q_probs(x0, al[t - 1]).permute(0, 2, 3, 1),       # 1 - beta_t == alpha_t
+        "theta_post": O.theta_post_t(xt, x0, a, c),
+        "theta_post_prob": O.theta_post_prob_t(xt, th, a, c),
+        "theta_post_prob_soft": O.theta_post_prob_t(th.roll(1, 0), th, a, c),
+        "kl": O.kl_clamped(torch.from_numpy(g[f"{tag}_theta_post"]), torch.from_numpy(g[f"{tag}_theta_post_prob"])),
+    }
+    for name, v in got.items():
+        np.testing.assert_allclose(v.numpy(), g[f"{tag}_{name}"], rtol=0, atol=5e-7, err_msg=name)
