@@ -711,3 +711,53 @@ def test_training_forward_pieces_full_size(U):
                                    rtol=0, atol=1e-6)
         xs = q.sample()
         assert xs.shape == x0.shape and torch.all(xs.sum(1) == 1)
+
+
+# ------------------------------------------------------------------------------------------ randomized conv geometry sweep
+def _random_conv_cases(n, seed):
+    r = np.random.default_rng(seed)
+    cases = []
+    while len(cases) < n:
+        k = int(r.choice([1, 3, 3]))
+        stride = 2 if (k == 3 and r.random() < 0.15) else 1
+        up = int(stride == 1 and k == 3 and r.random() < 0.15)
+        gn = int(r.random() < 0.6)
+        unit = 32 if gn else int(r.choice([4, 16, 32]))
+        c0 = unit * int(r.integers(1, 5))
+        c1 = 0
+        if r.random() < 0.3:                     # concatenated input; the seam must fall on a chunk boundary (16 or 32 channels)
+            c0 = 32 * int(r.integers(1, 4))
+            c1 = 32 * int(r.integers(1, 3)) if gn else 16 * int(r.integers(1, 4))
+        if gn and (c0 + c1) % 32:
+            continue
+        cout = int(r.choice([2, 6, 20, 32, 32, 64, 96, 128]))
+        H, W = int(r.integers(5, 41)), int(r.integers(5, 71))
+        if up:
+            H, W = min(H, 20), min(W, 36)
+        cases.append((c0, c1, cout, H, W, k, stride, up, gn, int(r.random() < 0.6), int(r.random() < 0.4), int(r.random() < 0.4)))
+    return cases
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", _random_conv_cases(40, 2024), ids=lambda c: "-".join(map(str, c)))
+def test_conv_random_geometry(U, case):
+    """40 seeded random (channels, image size, kernel, stride, upsample, GN, SiLU, emb, residual) combinations in the default
+    precision: every tile geometry, chunk width and ragged-edge path of the conv kernel against torch."""
+    test_conv(U, case, hip.PREC_F16X3)
+
+
+def _random_skip_cases(n, seed):
+    r = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        cout = 32 * int(r.integers(1, 5))
+        c0 = 32 * int(r.integers(1, 5))
+        c1 = 32 * int(r.integers(0, 4))
+        out.append((c0, c1, cout, int(r.integers(5, 41)), int(r.integers(5, 71))))
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c0,c1,cout,H,W", _random_skip_cases(12, 7))
+def test_conv_with_fused_skip_random_geometry(U, c0, c1, cout, H, W):
+    test_conv_with_fused_skip(U, hip.PREC_F16X3, c0, c1, cout, H, W)
