@@ -52,7 +52,7 @@ static inline void conv_ntiles(int Cout, int* ntiles_padded, int* NI) {
 static inline int conv_cin_pad(int Cin) { return cdiv(Cin, 32) * 32; }
 
 int launch_conv(const ccdm_conv_args& a, hipStream_t s);
-int launch_attention(const float* qkv, float* out, int N, int T, int C, int heads, int order, hipStream_t s);
+int launch_attention(const float* qkv, float* out, int N, int T, int Ta, int C, int heads, int order, hipStream_t s);
 int launch_posterior(const ccdm_post_args& a, hipStream_t s);
 
 }  // namespace ccdm

@@ -50,7 +50,7 @@ static int launch_step(ccdm_engine* e, int with_epilogue, hipStream_t s, bool pr
         const bool tap = profile && (int)i == e->prof_op && (size_t)(2 * e->prof_n + 1) < e->ev.size();
         if (tap) (void)hipEventRecord(e->ev[2 * e->prof_n], s);
         int rc = op.kind == 0 ? launch_conv(op.conv, s)
-                              : launch_attention(op.qkv, op.out, op.N, op.T, op.C, op.heads, op.order, s);
+                              : launch_attention(op.qkv, op.out, op.N, op.T, op.T, op.C, op.heads, op.order, s);
         if (tap) { (void)hipEventRecord(e->ev[2 * e->prof_n + 1], s); e->prof_n++; }
         if (rc) return rc;
     }

@@ -63,7 +63,7 @@ __global__ void k_gn_stats(const float* __restrict__ x, int HW, int C, int slice
 // ---------------------------------------------------------------------------------------------------
 template <int D>
 __global__ __launch_bounds__(64) void k_attention(const float* __restrict__ qkv, float* __restrict__ out,
-                                                  int T, int C, int heads, int order) {
+                                                  int T, int Ta, int C, int heads, int order) {      // Ta: token rows allocated per sample (>= T)
     __shared__ __attribute__((aligned(16))) float kt[64 * D];
     __shared__ __attribute__((aligned(16))) float vt[64 * D];
     const int lane = threadIdx.x;
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(64) void k_attention(const float* __restrict__ qkv,
     if (order == 0) { qoff = h * 3 * D; koff = qoff + D; voff = qoff + 2 * D; }      // legacy: head-major
     else { qoff = h * D; koff = C + h * D; voff = 2 * C + h * D; }                  // new: qkv-major
     const float scale = (float)(1.0 / sqrt(sqrt((double)D)));                      // ch^-1/4 on q and on k (python double -> fp32)
-    const float* base = qkv + (size_t)n * T * C3;
+    const float* base = qkv + (size_t)n * Ta * C3;
 
     float q[D], o[D];
     const int tq = t < T ? t : T - 1;
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(64) void k_attention(const float* __restrict__ qkv,
     }
     if (t < T) {
         const float inv = 1.0f / l;
-        float* dst = out + ((size_t)n * T + t) * C + h * D;
+        float* dst = out + ((size_t)n * Ta + t) * C + h * D;
 #pragma unroll
         for (int c = 0; c < D; c += 4)
             *reinterpret_cast<float4*>(dst + c) = make_float4(o[c] * inv, o[c + 1] * inv, o[c + 2] * inv, o[c + 3] * inv);
@@ -140,18 +140,19 @@ __global__ __launch_bounds__(64) void k_attention(const float* __restrict__ qkv,
 
 int launch_attention_mfma(const float* qkv, float* out, int N, int T, int C, int heads, int order, hipStream_t s);
 
-int launch_attention(const float* qkv, float* out, int N, int T, int C, int heads, int order, hipStream_t s) {
+int launch_attention(const float* qkv, float* out, int N, int T, int Ta, int C, int heads, int order, hipStream_t s) {
     CCDM_REQUIRE(qkv && out, "attention: null pointer");
     CCDM_REQUIRE(heads > 0 && C % heads == 0, "attention: C=%d not divisible by heads=%d", C, heads);
+    CCDM_REQUIRE(T > 0 && Ta >= T, "attention: T=%d, %d rows allocated per sample", T, Ta);
     const int D = C / heads;
     const bool force_valu = (order & 256) != 0;       // test hook: bit 8 selects the VALU kernel
     order &= 255;
-    if (D == 32 && T % 32 == 0 && !force_valu) return launch_attention_mfma(qkv, out, N, T, C, heads, order, s);
+    if (D == 32 && T % 32 == 0 && Ta == T && !force_valu) return launch_attention_mfma(qkv, out, N, T, C, heads, order, s);
     dim3 grid(cdiv(T, 64), heads, N), block(64);
     switch (D) {
-        case 16: hipLaunchKernelGGL(k_attention<16>, grid, block, 0, s, qkv, out, T, C, heads, order); break;
-        case 32: hipLaunchKernelGGL(k_attention<32>, grid, block, 0, s, qkv, out, T, C, heads, order); break;
-        case 64: hipLaunchKernelGGL(k_attention<64>, grid, block, 0, s, qkv, out, T, C, heads, order); break;
+        case 16: hipLaunchKernelGGL(k_attention<16>, grid, block, 0, s, qkv, out, T, Ta, C, heads, order); break;
+        case 32: hipLaunchKernelGGL(k_attention<32>, grid, block, 0, s, qkv, out, T, Ta, C, heads, order); break;
+        case 64: hipLaunchKernelGGL(k_attention<64>, grid, block, 0, s, qkv, out, T, Ta, C, heads, order); break;
         default: return fail("attention: head width %d not built (16/32/64)", D);
     }
     CCDM_CHECK_LAUNCH("attention");
@@ -240,7 +241,7 @@ extern "C" int ccdm_gn_stats(const float* x, int N, int HW, int C, int slices, d
 }
 
 extern "C" int ccdm_attention(const float* qkv, float* out, int N, int T, int C, int heads, int order, void* stream) {
-    return launch_attention(qkv, out, N, T, C, heads, order, (hipStream_t)stream);
+    return launch_attention(qkv, out, N, T, T, C, heads, order, (hipStream_t)stream);
 }
 
 extern "C" int ccdm_time_table(const float* sinus, int S, int mc, const float* w0, const float* b0,
@@ -274,5 +275,82 @@ extern "C" int ccdm_onehot_to_xin(const uint8_t* idx, float* xin, int N, int HW,
     hipLaunchKernelGGL(k_onehot_to_xin, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        idx, xin, K, xin_stride, npix);
     CCDM_CHECK_LAUNCH("onehot_to_xin");
+    return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// DINO ViT-S/8 key-feature extractor: the pieces the conv / attention kernels do not cover.
+// The network itself (facebookresearch/dino vision_transformer.py, loaded by the reference through torch.hub,
+// ddpm/models/dino.py:58-82) is third-party code that is absent from /root/reference: restated from its published form.
+// ---------------------------------------------------------------------------------------------------
+namespace ccdm {
+
+// nn.LayerNorm(C, eps) over the last axis: one wave per token row, the row in registers, two passes (mean, then centred
+// variance) like ATen's; C <= 64 * LN_MAX_PER_LANE
+constexpr int LN_MAX_PER_LANE = 24;
+__global__ __launch_bounds__(256) void k_layernorm(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                   float eps, long rows, int C, float* __restrict__ out) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + row * C;
+    float v[LN_MAX_PER_LANE];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = c < C ? xr[c] : 0.f;
+        sum += v[i];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    const float mean = sum / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+        const int c = lane + 64 * i;
+        const float d = c < C ? v[i] - mean : 0.f;
+        sq = fmaf(d, d, sq);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off);
+    const float rstd = 1.0f / sqrtf(sq / (float)C + eps);
+    float* orow = out + row * C;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_PER_LANE; ++i) {
+        const int c = lane + 64 * i;
+        if (c < C) orow[c] = (v[i] - mean) * rstd * gamma[c] + beta[c];
+    }
+}
+
+// nn.GELU() (exact, erf form)
+__global__ __launch_bounds__(256) void k_gelu(const float* __restrict__ x, size_t n, float* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = x[i];
+        out[i] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    }
+}
+
+}  // namespace ccdm
+
+extern "C" int ccdm_attention_ex(const float* qkv, float* out, int N, int T, int T_alloc, int C, int heads, int order, void* stream) {
+    return ccdm::launch_attention(qkv, out, N, T, T_alloc, C, heads, order, (hipStream_t)stream);
+}
+
+extern "C" int ccdm_layernorm(const float* x, const float* gamma, const float* beta, float eps, long rows, int C, float* out, void* stream) {
+    if (!x || !gamma || !beta || !out) return ccdm::fail("ccdm_layernorm: null pointer");
+    if (rows <= 0 || C <= 0 || C > 64 * ccdm::LN_MAX_PER_LANE) return ccdm::fail("ccdm_layernorm: rows=%ld C=%d (C <= %d)", rows, C, 64 * ccdm::LN_MAX_PER_LANE);
+    hipLaunchKernelGGL(ccdm::k_layernorm, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, eps, rows, C, out);
+    CCDM_CHECK_LAUNCH("layernorm");
+    return 0;
+}
+
+extern "C" int ccdm_gelu(const float* x, size_t n, float* out, void* stream) {
+    if (!x || !out) return ccdm::fail("ccdm_gelu: null pointer");
+    if (!n) return 0;
+    const size_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(ccdm::k_gelu, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, (hipStream_t)stream, x, n, out);
+    CCDM_CHECK_LAUNCH("gelu");
     return 0;
 }

@@ -175,6 +175,20 @@ int ccdm_theta_post(const float* xt /*dev [N,K,HW]*/, const float* x0 /*dev [N,K
                     int N, int K, int HW, int prob_mode, float* out /*dev [N,K,HW]*/, void* stream);
 int ccdm_kl_clamped(const float* p, const float* q, size_t n, float floor, float* out, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * DINO ViT-S/8 key-feature extractor (reference call sites ddpm/models/dino.py:211-229,279-305 and
+ * condition_encoder.py:26-46; the network itself is facebookresearch/dino's VisionTransformer, fetched by the reference
+ * with torch.hub (dino.py:58-82) and therefore not part of /root/reference: restated from its published form).
+ * The linear layers run on ccdm_conv2d as 1x1 convs over a [N, T_alloc/16, 16, C] token image; these cover the rest:
+ *   ccdm_attention_ex : ccdm_attention with T_alloc >= T token rows allocated per sample (only the first T are tokens)
+ *   ccdm_layernorm    : nn.LayerNorm(C, eps) over the last axis of [rows, C]
+ *   ccdm_gelu         : nn.GELU(), exact erf form
+ * ------------------------------------------------------------------------------------------------- */
+int ccdm_attention_ex(const float* qkv /*dev [N,T_alloc,3C]*/, float* out /*dev [N,T_alloc,C]*/, int N, int T, int T_alloc, int C,
+                      int heads, int order, void* stream);
+int ccdm_layernorm(const float* x, const float* gamma, const float* beta, float eps, long rows, int C, float* out, void* stream);
+int ccdm_gelu(const float* x, size_t n, float* out, void* stream);
+
 /* debugging aid: phase timestamps (s_memtime) one block of the last conv launched with ablation bit 16 recorded */
 int ccdm_debug_read_timeline(unsigned long long* host, int n);
 

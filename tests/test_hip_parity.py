@@ -761,3 +761,64 @@ def _random_skip_cases(n, seed):
 @pytest.mark.parametrize("c0,c1,cout,H,W", _random_skip_cases(12, 7))
 def test_conv_with_fused_skip_random_geometry(U, c0, c1, cout, H, W):
     test_conv_with_fused_skip(U, hip.PREC_F16X3, c0, c1, cout, H, W)
+
+
+# ------------------------------------------------------------------------------------------ DINO ViT-S/8 key features (N4)
+@pytest.mark.gpu
+def test_layernorm_and_gelu(U):
+    g = np.random.default_rng(3)
+    x = torch.from_numpy((g.standard_normal((37, 5, 384)) * 3 + 0.7).astype(np.float32))
+    gam, bet = torch.from_numpy(g.standard_normal(384).astype(np.float32)), torch.from_numpy(g.standard_normal(384).astype(np.float32))
+    lib = hip.load()
+    xd, out = x.to(U.DEV), torch.empty_like(x, device=U.DEV)
+    gd, bd = gam.to(U.DEV), bet.to(U.DEV)
+    hip.check(lib.ccdm_layernorm(xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), 1e-6, 37 * 5, 384, out.data_ptr(), 0), "ln")
+    np.testing.assert_allclose(out.cpu().numpy(), F.layer_norm(x, (384,), gam, bet, 1e-6).numpy(), rtol=0, atol=5e-6)
+    hip.check(lib.ccdm_gelu(xd.data_ptr(), x.numel(), out.data_ptr(), 0), "gelu")
+    np.testing.assert_allclose(out.cpu().numpy(), F.gelu(x).numpy(), rtol=0, atol=2e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W", [(64, 96), (224, 224), (40, 72)])
+def test_dino_key_descriptors_vs_oracle(U, H, W):
+    """ViT-S/8 layer-11 keys through the HIP path vs the CPU restatement of the published network on synthetic weights
+    (parity unpinned: no reference output exists for this third-party network; see oracle/dino_oracle.py)."""
+    from oracle import dino_oracle
+    from ccdm_stochastic_segmentation_amd.dino import DinoViT, make_synthetic_vit_state_dict, vit_param_shapes
+    sd = make_synthetic_vit_state_dict("dino_vits8", 5)
+    assert sum(int(np.prod(s)) for s in vit_param_shapes().values()) == 21_670_272        # ViT-S/8 parameter count
+    enc = DinoViT("dino_vits8", False, "concat_pixels_concat_features", stride=8, state_dict=sd)
+    x = torch.from_numpy(np.random.default_rng(H).standard_normal((2, 3, H, W)).astype(np.float32))
+    got = enc(x.to(U.DEV))
+    ref = dino_oracle.extract_key_descriptors({k: torch.from_numpy(v) for k, v in sd.items()}, x)
+    assert got.shape == ref.shape == (2, 384, H // 8, W // 8)
+    err = (got.cpu() - ref).abs().max().item()
+    assert err < 2e-4 * max(1.0, ref.abs().max().item()), err
+    with pytest.raises(NotImplementedError):
+        enc.extractor.extract_descriptors(x.to(U.DEV), 11, facet="token")
+
+
+@pytest.mark.gpu
+def test_dino_features_feed_the_sampler(U):
+    """C4-shaped wiring: image -> DinoViT (HIP) -> feature_condition of DenoisingModel.forward, like trainer/evaluator code does
+    (condition_encoder.py:41-44 -> diffusion_denoising.py:144)."""
+    from ccdm_stochastic_segmentation_amd.dino import DinoViT, make_synthetic_vit_state_dict
+    from ccdm_stochastic_segmentation_amd.models import build_model
+    from ccdm_stochastic_segmentation_amd.unet_spec import make_synthetic_state_dict
+    fce = dict(type="dino", model="dino_vits8", channels=384, conditioning="concat_pixels_concat_features", output_stride=8,
+               scale="single", train=False, source_layer=11, target_layer=10)
+    K, H, W, N = 20, 64, 64, 2
+    model = build_model(4, "cosine", {"s": 0.008}, [(3, H, W), (K, H, W)], (3, H, W), "unet_openai",
+                        dict(LIDC_BP, channel_mult=[1, 1, 2, 2, 4, 4]), "datasets.cityscapes", "confidence", fce)
+    model.unet.load_state_dict({k: torch.from_numpy(v) for k, v in make_synthetic_state_dict(model.unet.spec, 2).items()}, strict=True)
+    model = model.to(U.DEV).eval()
+    model.prec, model.rng = hip.PREC_F16X3, "philox"
+    enc = DinoViT(fce["model"], fce["train"], fce["conditioning"], stride=fce["output_stride"], state_dict=make_synthetic_vit_state_dict(seed=4))
+    g = np.random.default_rng(9)
+    img = torch.from_numpy(g.uniform(-1, 1, (N, 3, H, W)).astype(np.float32)).to(U.DEV)
+    feat = enc(img)
+    assert feat.shape == (N, 384, H // 8, W // 8)
+    x = torch.nn.functional.one_hot(torch.from_numpy(g.integers(0, K, (N, H, W))), K).permute(0, 3, 1, 2).float().to(U.DEV)
+    out = model(x, img, feat)["diffusion_out"]
+    assert out.shape == (N, K, H, W) and torch.isfinite(out).all()
+    np.testing.assert_allclose(out.sum(1).cpu().numpy(), 1.0, atol=1e-5)

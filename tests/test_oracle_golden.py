@@ -264,3 +264,21 @@ def test_training_forward_pieces_match_reference(golden, tag):
     }
     for name, v in got.items():
         np.testing.assert_allclose(v.numpy(), g[f"{tag}_{name}"], rtol=0, atol=5e-7, err_msg=name)
+
+
+# ------------------------------------------------------------------------------------------ DINO ViT-S/8 key features (N4)
+def test_dino_oracle_descriptor_layout():
+    """PARITY UNPINNED (no reference output exists for the torch.hub network).  What can be pinned on the CPU is the reference's own
+    wrapper arithmetic (dino.py:176-183,297-305): descriptor channel = d_index * heads + head, class token dropped, row-major patches;
+    and that a 224x224 input uses the position embedding unresized."""
+    from oracle import dino_oracle as D
+    from ccdm_stochastic_segmentation_amd.dino import make_synthetic_vit_state_dict
+    sd = {k: torch.from_numpy(v) for k, v in make_synthetic_vit_state_dict("dino_vits8", 1).items()}
+    x = torch.from_numpy(np.random.default_rng(0).standard_normal((1, 3, 32, 48)).astype(np.float32))
+    desc = D.extract_key_descriptors(sd, x, layer=1)
+    t = D.vit_block(sd, 0, D.vit_tokens(sd, x, 8), 6)
+    k = D.vit_block_qkv(sd, 1, t).reshape(1, -1, 3, 6, 64)[:, :, 1]          # [B, t, h, d]
+    for (yy, xx, h, d) in [(0, 0, 0, 0), (3, 5, 4, 17), (2, 1, 5, 63)]:
+        assert desc[0, d * 6 + h, yy, xx].item() == pytest.approx(k[0, 1 + yy * 6 + xx, h, d].item(), abs=1e-6)
+    assert D.interpolate_pos_encoding(sd["pos_embed"], 224, 224, 8) is sd["pos_embed"]
+    assert D.interpolate_pos_encoding(sd["pos_embed"], 256, 512, 8).shape == (1, 1 + 32 * 64, 384)
