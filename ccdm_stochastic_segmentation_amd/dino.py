@@ -11,7 +11,7 @@ ccdm_attention_ex).  torch only moves memory: patch unfolding, token padding, th
 
 PARITY UNPINNED: the network definition and weights come from `torch.hub.load('facebookresearch/dino:main', ...)` in the
 reference (dino.py:58-82) — third-party, not in /root/reference, no network here.  The state_dict layout below is that
-repository's published VisionTransformer; `oracle/dino_oracle.py` restates its forward, and the tests compare against that on
+repository's published VisionTransformer; the test tree carries a CPU restatement of its forward, and the tests compare against that on
 synthetic weights.  There is no hub download: pass `state_dict=` (e.g. `torch.load('dino_deitsmall8_pretrain.pth')`).
 """
 import ctypes as C
