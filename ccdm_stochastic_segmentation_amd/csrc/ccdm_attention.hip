@@ -1,4 +1,5 @@
-// Self-attention core on the matrix cores (head width 32, every reference config: num_head_channels: 32).
+// Self-attention core on the matrix cores: head width 32 (every reference U-Net config: num_head_channels: 32) and 64 (the DINO
+// ViT-S/8 feature encoder, whose token rows may be padded: Ta rows allocated per sample, T of them tokens).
 //
 //   softmax((q*s)(k*s)^T) v   per (sample, head),   s = 32^-1/4        unet.py:343-360 (legacy) / :376-395 (new order)
 //
@@ -16,7 +17,7 @@
 namespace ccdm {
 
 static constexpr int KT = 64;              // keys per tile
-static constexpr int KROW = 144;           // bytes per K-tile row: 32 hi | 32 lo halfs | 16 pad  (36 dwords: conflict-free b128)
+template <int D> struct KRow { static constexpr int B = 4 * D + 16; };   // bytes per K-tile row: D hi | D lo halfs | 16 pad (36 / 68 dwords: conflict-free b128)
 static constexpr int VROW = 2 * KT * 2 + 8;  // bytes per V^T row: 64 hi | 64 lo halfs | 8 pad (66 dwords... 8-B aligned, b64 reads)
 
 __device__ __forceinline__ void split4(const float4 v, f16x4& hi, f16x4& lo) {
@@ -25,10 +26,10 @@ __device__ __forceinline__ void split4(const float4 v, f16x4& hi, f16x4& lo) {
     lo[2] = (_Float16)(v.z - (float)hi[2]); lo[3] = (_Float16)(v.w - (float)hi[3]);
 }
 
-template <int WAVES>
+template <int WAVES, int D>
 __global__ __launch_bounds__(WAVES * 64) void k_attention_mfma(const float* __restrict__ qkv, float* __restrict__ out,
-                                                              int T, int C, int order) {
-    constexpr int D = 32, NT = WAVES * 64;
+                                                              int T, int Ta, int C, int order) {
+    constexpr int NT = WAVES * 64, KROW = KRow<D>::B, DS = D / 16 /* 16-wide k-steps over d */, DM = D / 32 /* 32-row tiles of d */;
     __shared__ __attribute__((aligned(16))) char kt[KT * KROW];
     __shared__ __attribute__((aligned(16))) char vt[D * VROW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -39,15 +40,15 @@ __global__ __launch_bounds__(WAVES * 64) void k_attention_mfma(const float* __re
     if (order == 0) { qoff = h * 3 * D; koff = qoff + D; voff = qoff + 2 * D; }
     else { qoff = h * D; koff = C + h * D; voff = 2 * C + h * D; }
     const float scale = (float)(1.0 / sqrt(sqrt((double)D)));
-    const float* base = qkv + (size_t)n * T * C3;
+    const float* base = qkv + (size_t)n * Ta * C3;
     const int qi = lane & 31, half = lane >> 5;
 
     // ---- Q^T fragment (B operand): column = query, k-slot (half, j) = d 16*s + 8*half + j ----
-    f16x8 qh[2], ql[2];
+    f16x8 qh[DS], ql[DS];
     {
         const int tq = min(q0 + qi, T - 1);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < DS; ++s) {
             const float* p = base + (size_t)tq * C3 + qoff + 16 * s + 8 * half;
             float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
             a.x *= scale; a.y *= scale; a.z *= scale; a.w *= scale;
@@ -58,16 +59,18 @@ __global__ __launch_bounds__(WAVES * 64) void k_attention_mfma(const float* __re
             for (int j = 0; j < 4; ++j) { qh[s][j] = h0[j]; qh[s][4 + j] = h1[j]; ql[s][j] = l0[j]; ql[s][4 + j] = l1[j]; }
         }
     }
-    f32x16 o;
+    f32x16 o[DM];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    for (int mt = 0; mt < DM; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[mt][r] = 0.f;
     float m = -INFINITY, l = 0.f;
 
     for (int j0 = 0; j0 < T; j0 += KT) {
         __syncthreads();
         // ---- stage K (row-major, scaled) and V (transposed) tiles as fp16 hi/lo ----
         for (int item = tid; item < KT * (D / 4); item += NT) {
-            const int key = item >> 3, c4 = item & 7;
+            const int key = item / (D / 4), c4 = item % (D / 4);
             float4 kv = make_float4(0, 0, 0, 0), vv = make_float4(0, 0, 0, 0);
             if (j0 + key < T) {
                 const float* p = base + (size_t)(j0 + key) * C3;
@@ -78,7 +81,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_attention_mfma(const float* __re
             f16x4 hi, lo;
             split4(kv, hi, lo);
             *reinterpret_cast<f16x4*>(kt + key * KROW + 8 * c4) = hi;
-            *reinterpret_cast<f16x4*>(kt + key * KROW + 64 + 8 * c4) = lo;
+            *reinterpret_cast<f16x4*>(kt + key * KROW + 2 * D + 8 * c4) = lo;
             split4(vv, hi, lo);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -97,10 +100,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_attention_mfma(const float* __re
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {      // A = K rows (key = 32*st + lane&31), k-slot (half, j) = d 16*s + 8*half + j
+                for (int s = 0; s < DS; ++s) {     // A = K rows (key = 32*st + lane&31), k-slot (half, j) = d 16*s + 8*half + j
                     const char* p = kt + (32 * st + qi) * KROW + 32 * s + 16 * half;
                     const f16x8 kh = *reinterpret_cast<const f16x8*>(p);
-                    const f16x8 kl = *reinterpret_cast<const f16x8*>(p + 64);
+                    const f16x8 kl = *reinterpret_cast<const f16x8*>(p + 2 * D);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], acc, 0, 0, 0);
@@ -120,7 +123,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_attention_mfma(const float* __re
         m = mx;
         l *= corr;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[r] *= corr;
+        for (int mt = 0; mt < DM; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[mt][r] *= corr;
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
             if (st < nsub) {
@@ -138,15 +143,18 @@ __global__ __launch_bounds__(WAVES * 64) void k_attention_mfma(const float* __re
                         ph[j] = (_Float16)pv;
                         pl[j] = (_Float16)(pv - (float)ph[j]);
                     }
-                    const char* vp = vt + qi * VROW + 2 * (32 * st + 16 * s + 4 * half);     // row d = lane&31
-                    f16x8 vh, vl;
-                    const f16x4 vh0 = *reinterpret_cast<const f16x4*>(vp), vh1 = *reinterpret_cast<const f16x4*>(vp + 16);
-                    const f16x4 vl0 = *reinterpret_cast<const f16x4*>(vp + 2 * KT), vl1 = *reinterpret_cast<const f16x4*>(vp + 2 * KT + 16);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { vh[j] = vh0[j]; vh[4 + j] = vh1[j]; vl[j] = vl0[j]; vl[4 + j] = vl1[j]; }
-                    o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o, 0, 0, 0);
-                    o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o, 0, 0, 0);
-                    o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o, 0, 0, 0);
+                    for (int mt = 0; mt < DM; ++mt) {
+                        const char* vp = vt + (32 * mt + qi) * VROW + 2 * (32 * st + 16 * s + 4 * half);     // row d = 32*mt + lane&31
+                        f16x8 vh, vl;
+                        const f16x4 vh0 = *reinterpret_cast<const f16x4*>(vp), vh1 = *reinterpret_cast<const f16x4*>(vp + 16);
+                        const f16x4 vl0 = *reinterpret_cast<const f16x4*>(vp + 2 * KT), vl1 = *reinterpret_cast<const f16x4*>(vp + 2 * KT + 16);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { vh[j] = vh0[j]; vh[4 + j] = vh1[j]; vl[j] = vl0[j]; vl[4 + j] = vl1[j]; }
+                        o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o[mt], 0, 0, 0);
+                        o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, o[mt], 0, 0, 0);
+                        o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, o[mt], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -155,19 +163,29 @@ __global__ __launch_bounds__(WAVES * 64) void k_attention_mfma(const float* __re
     if (q0 + qi < T) {
         const float inv = 1.0f / l;
         // o[r] = O[query = lane&31][d = (r&3) + 8*(r>>2) + 4*half]: four float4 rows of 4 consecutive d each
-        float* dst = out + ((size_t)n * T + q0 + qi) * C + h * D + 4 * half;
+        float* dst = out + ((size_t)n * Ta + q0 + qi) * C + h * D + 4 * half;
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<float4*>(dst + 8 * g) = make_float4(o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv);
+        for (int mt = 0; mt < DM; ++mt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(dst + 32 * mt + 8 * g) =
+                    make_float4(o[mt][4 * g] * inv, o[mt][4 * g + 1] * inv, o[mt][4 * g + 2] * inv, o[mt][4 * g + 3] * inv);
     }
 }
 
-int launch_attention_mfma(const float* qkv, float* out, int N, int T, int C, int heads, int order, hipStream_t s) {
+int launch_attention_mfma(const float* qkv, float* out, int N, int T, int Ta, int C, int heads, int order, hipStream_t s) {
+    const int D = C / heads;
     const int waves = T >= 128 ? 4 : (T >= 64 ? 2 : 1);
     dim3 grid(cdiv(T, 32 * waves), heads, N);
-    if (waves == 4) hipLaunchKernelGGL(k_attention_mfma<4>, grid, dim3(256), 0, s, qkv, out, T, C, order);
-    else if (waves == 2) hipLaunchKernelGGL(k_attention_mfma<2>, grid, dim3(128), 0, s, qkv, out, T, C, order);
-    else hipLaunchKernelGGL(k_attention_mfma<1>, grid, dim3(64), 0, s, qkv, out, T, C, order);
+    if (D == 64) {
+        if (waves == 4) hipLaunchKernelGGL((k_attention_mfma<4, 64>), grid, dim3(256), 0, s, qkv, out, T, Ta, C, order);
+        else if (waves == 2) hipLaunchKernelGGL((k_attention_mfma<2, 64>), grid, dim3(128), 0, s, qkv, out, T, Ta, C, order);
+        else hipLaunchKernelGGL((k_attention_mfma<1, 64>), grid, dim3(64), 0, s, qkv, out, T, Ta, C, order);
+    } else {
+        if (waves == 4) hipLaunchKernelGGL((k_attention_mfma<4, 32>), grid, dim3(256), 0, s, qkv, out, T, Ta, C, order);
+        else if (waves == 2) hipLaunchKernelGGL((k_attention_mfma<2, 32>), grid, dim3(128), 0, s, qkv, out, T, Ta, C, order);
+        else hipLaunchKernelGGL((k_attention_mfma<1, 32>), grid, dim3(64), 0, s, qkv, out, T, Ta, C, order);
+    }
     CCDM_CHECK_LAUNCH("attention_mfma");
     return 0;
 }

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(64) void k_attention(const float* __restrict__ qkv,
     }
 }
 
-int launch_attention_mfma(const float* qkv, float* out, int N, int T, int C, int heads, int order, hipStream_t s);
+int launch_attention_mfma(const float* qkv, float* out, int N, int T, int Ta, int C, int heads, int order, hipStream_t s);
 
 int launch_attention(const float* qkv, float* out, int N, int T, int Ta, int C, int heads, int order, hipStream_t s) {
     CCDM_REQUIRE(qkv && out, "attention: null pointer");
@@ -147,7 +147,8 @@ int launch_attention(const float* qkv, float* out, int N, int T, int Ta, int C, 
     const int D = C / heads;
     const bool force_valu = (order & 256) != 0;       // test hook: bit 8 selects the VALU kernel
     order &= 255;
-    if (D == 32 && T % 32 == 0 && Ta == T && !force_valu) return launch_attention_mfma(qkv, out, N, T, C, heads, order, s);
+    // head width 32: the U-Net path (token count a multiple of 32, dense rows); head width 64: the ViT feature encoder (any T, padded rows)
+    if (((D == 32 && T % 32 == 0 && Ta == T) || D == 64) && !force_valu) return launch_attention_mfma(qkv, out, N, T, Ta, C, heads, order, s);
     dim3 grid(cdiv(T, 64), heads, N), block(64);
     switch (D) {
         case 16: hipLaunchKernelGGL(k_attention<16>, grid, block, 0, s, qkv, out, T, Ta, C, heads, order); break;

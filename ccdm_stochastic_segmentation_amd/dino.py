@@ -138,12 +138,13 @@ class ViTExtractor:
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
-    def _linear(self, x: torch.Tensor, w, resid: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def _linear(self, x: torch.Tensor, w, resid: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """x: [N, R, TOKW, Cin] token image -> [N, R, TOKW, Cout] = x @ W^T + b (+ resid), one ccdm_conv2d launch."""
         wdev, bdev, cout, cin = w
         N, R, Wd, Cin = x.shape
         assert Cin == cin, (Cin, cin)
-        out = torch.empty((N, R, Wd, cout), device=self.device, dtype=torch.float32)
+        if out is None:
+            out = torch.empty((N, R, Wd, cout), device=self.device, dtype=torch.float32)
         a = hip.ConvArgs()
         a.in0, a.C0 = x.data_ptr(), Cin
         a.eps, a.act = 1e-5, hip.ACT_NONE
@@ -157,23 +158,41 @@ class ViTExtractor:
         hip.check(self.lib.ccdm_conv2d(C.byref(a), self._stream()), "vit linear")
         return out
 
-    def _layernorm(self, x: torch.Tensor, gb) -> torch.Tensor:
-        out = torch.empty_like(x)
+    def _layernorm(self, x: torch.Tensor, gb, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        out = torch.empty_like(x) if out is None else out
         Cc = x.shape[-1]
         hip.check(self.lib.ccdm_layernorm(x.data_ptr(), gb[0].data_ptr(), gb[1].data_ptr(), LN_EPS, x.numel() // Cc, Cc, out.data_ptr(), self._stream()), "layernorm")
         return out
 
-    def _gelu(self, x: torch.Tensor) -> torch.Tensor:
-        out = torch.empty_like(x)
+    def _gelu(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        out = torch.empty_like(x) if out is None else out
         hip.check(self.lib.ccdm_gelu(x.data_ptr(), x.numel(), out.data_ptr(), self._stream()), "gelu")
         return out
 
-    def _attention(self, qkv: torch.Tensor, T: int) -> torch.Tensor:
+    def _attention(self, qkv: torch.Tensor, T: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         N, R, Wd, C3 = qkv.shape
         Cc = C3 // 3
-        out = torch.zeros((N, R, Wd, Cc), device=self.device, dtype=torch.float32)     # padding rows stay 0
+        if out is None:
+            out = torch.zeros((N, R, Wd, Cc), device=self.device, dtype=torch.float32)     # padding rows stay 0
         hip.check(self.lib.ccdm_attention_ex(qkv.data_ptr(), out.data_ptr(), N, T, R * Wd, Cc, self.cfg["heads"], 1, self._stream()), "vit attention")
         return out
+
+    def _workspace(self, N: int, Ta: int, H: int, W: int) -> Dict[str, torch.Tensor]:
+        key = (N, H, W)
+        if getattr(self, "_ws_key", None) != key:
+            d, R, p = self.cfg["dim"], Ta // TOKW, self.p
+            T = 1 + (H // p) * (W // p)
+            mk = lambda c: torch.zeros((N, R, TOKW, c), device=self.device, dtype=torch.float32)
+            # what is added after the patch projection: position embedding; the class row gets cls + pos[0] - bias (its "projection" is the bias)
+            pos = self._pos_for(H, W)
+            add = torch.zeros((Ta, d), dtype=torch.float32)
+            add[:T] = pos
+            add[0] = self.cls_token[0] + pos[0] - self.patch_bias
+            self._ws = dict(xa=mk(d), xb=mk(d), ln=mk(d), qkv=mk(3 * d), att=mk(d), h=mk(self.cfg["mlp_ratio"] * d), g=mk(self.cfg["mlp_ratio"] * d),
+                            tok=torch.zeros((N, Ta, 3 * p * p), device=self.device, dtype=torch.float32),
+                            add=add.to(self.device).unsqueeze(0).expand(N, Ta, d).contiguous())
+            self._ws_key = key
+        return self._ws
 
     # ------------------------------------------------------------------ forward
     def _qkv_of_layer(self, batch: torch.Tensor, layer: int) -> torch.Tensor:
@@ -188,25 +207,24 @@ class ViTExtractor:
         T = 1 + hp * wp
         Ta = (T + 31) // 32 * 32
         dev = self.device
-        # patches in (c, ky, kx) order = the flattened conv weight's; row 0 (class token) and the padding rows are zero
-        patches = batch.float().unfold(2, p, p).unfold(3, p, p).permute(0, 2, 3, 1, 4, 5).reshape(N, hp * wp, 3 * p * p)
-        tok_in = torch.zeros((N, Ta, 3 * p * p), device=dev, dtype=torch.float32)
-        tok_in[:, 1:T] = patches
-        # what is added after the patch projection: position embedding; the class row gets cls + pos[0] - bias (its "projection" is the bias)
-        pos = self._pos_for(H, W)
-        add = torch.zeros((Ta, d), dtype=torch.float32)
-        add[:T] = pos
-        add[0] = self.cls_token[0] + pos[0] - self.patch_bias
-        add = add.to(dev).unsqueeze(0).expand(N, Ta, d).contiguous()
-        x = self._linear(tok_in.view(N, Ta // TOKW, TOKW, -1), self.w_patch, resid=add.view(N, Ta // TOKW, TOKW, d))
+        ws = self._workspace(N, Ta, H, W)
+        # patches in (c, ky, kx) order = the flattened conv weight's, gathered straight into the token buffer; row 0 (class token)
+        # and the padding rows stay zero
+        tok_in = ws["tok"]
+        tok_in[:, 1:T].view(N, hp, wp, 3, p, p).copy_(batch.float().unfold(2, p, p).unfold(3, p, p).permute(0, 2, 3, 1, 4, 5))
+        add = ws["add"]
+        # (every buffer of this (batch, image size) is allocated once and reused: per-call device allocations of this size make the
+        #  caching allocator free and re-map memory, which cost 50-70 ms per call against 12 ms of kernels)
+        x = self._linear(tok_in.view(N, Ta // TOKW, TOKW, -1), self.w_patch, resid=add.view(N, Ta // TOKW, TOKW, d), out=ws["xa"])
+        spare = ws["xb"]
         for i in range(layer + 1):
             blk = self.blocks[i]
-            qkv = self._linear(self._layernorm(x, blk["n1"]), blk["qkv"])
+            qkv = self._linear(self._layernorm(x, blk["n1"], out=ws["ln"]), blk["qkv"], out=ws["qkv"])
             if i == layer:
                 return qkv.view(N, Ta, 3 * d), T, hp, wp
-            x = self._linear(self._attention(qkv, T), blk["proj"], resid=x)
-            h = self._gelu(self._linear(self._layernorm(x, blk["n2"]), blk["fc1"]))
-            x = self._linear(h, blk["fc2"], resid=x)
+            x2 = self._linear(self._attention(qkv, T, out=ws["att"]), blk["proj"], resid=x, out=spare)
+            h = self._gelu(self._linear(self._layernorm(x2, blk["n2"], out=ws["ln"]), blk["fc1"], out=ws["h"]), out=ws["g"])
+            x, spare = self._linear(h, blk["fc2"], resid=x2, out=x), x2          # the residual stream alternates between the two buffers
         raise AssertionError
 
     def extract_descriptors(self, batch: torch.Tensor, layers: Union[int, list] = 11, facet: str = "key", include_cls: bool = False,

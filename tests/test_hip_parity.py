@@ -822,3 +822,24 @@ def test_dino_features_feed_the_sampler(U):
     out = model(x, img, feat)["diffusion_out"]
     assert out.shape == (N, K, H, W) and torch.isfinite(out).all()
     np.testing.assert_allclose(out.sum(1).cpu().numpy(), 1.0, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,T,Ta", [(128, 64, 64), (384, 257, 272), (128, 100, 128), (384, 1025, 1040)])
+def test_attention_head_width_64_padded_rows(U, C, T, Ta):
+    """ccdm_attention_ex: head width 64 (the ViT feature encoder) on the MFMA kernel, T tokens in Ta allocated rows per sample;
+    the padding rows of the output are not written."""
+    rng = np.random.default_rng(C + T)
+    heads = C // 64
+    qkv = rnd(rng, 2, 3 * C, T) * 1.2
+    ref = O.qkv_attention_new(qkv, heads)                                   # [N, C, T]
+    buf = torch.full((2, Ta, 3 * C), 7.0)
+    buf[:, :T] = qkv.permute(0, 2, 1)
+    out = torch.full((2, Ta, C), -5.0, device=U.DEV)
+    lib = hip.load()
+    bd = buf.to(U.DEV)
+    hip.check(lib.ccdm_attention_ex(bd.data_ptr(), out.data_ptr(), 2, T, Ta, C, heads, 1, 0), "attention_ex")
+    torch.cuda.synchronize()
+    got = out.cpu()
+    np.testing.assert_allclose(got[:, :T].permute(0, 2, 1).numpy(), ref.numpy(), rtol=0, atol=1e-5)
+    assert torch.all(got[:, T:] == -5.0)

@@ -28,3 +28,28 @@ for (N, H, W) in [(8, 256, 512), (64, 128, 128), (1, 256, 512)]:
     att = 11 * 2 * T * d                                                      # QK^T and PV MACs per token
     flops = 2.0 * N * T * (lin + att)
     print(f"N={N} {H}x{W} (T={T}): {ms:8.2f} ms per batch, {ms / N:7.2f} ms per image, {flops / ms / 1e9:7.1f} TFLOP/s")
+
+# where the time goes (8 x 256x512): rocprofv3-free breakdown with events around each kind of launch
+import collections
+acc = collections.defaultdict(float)
+ext = enc.extractor
+orig = {k: getattr(ext, k) for k in ("_linear", "_layernorm", "_gelu", "_attention")}
+
+
+def timed(name):
+    def f(*a, **k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = orig[name](*a, **k)
+        e1.record()
+        torch.cuda.synchronize()
+        acc[name] += e0.elapsed_time(e1)
+        return r
+    return f
+
+
+for k in orig:
+    setattr(ext, k, timed(k))
+x = torch.randn((8, 3, 256, 512), device=DEV)
+enc(x)
+print("breakdown, 8 x 256x512 (ms):", {k: round(v, 2) for k, v in acc.items()})
