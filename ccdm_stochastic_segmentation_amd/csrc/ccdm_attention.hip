@@ -66,17 +66,33 @@ __global__ __launch_bounds__(WAVES * 64) void k_attention_mfma(const float* __re
         for (int r = 0; r < 16; ++r) o[mt][r] = 0.f;
     float m = -INFINITY, l = 0.f;
 
+    // K/V staging items of a key tile: KT keys x D/4 float4 columns over NT threads.  The next tile's are requested (into registers,
+    // rows clamped into the sample; rows beyond T are zeroed at staging) before the current tile's MFMAs, so their round trip to L2/HBM
+    // runs under the matrix work instead of in front of the next staging pass.
+    constexpr int NSTG = KT * (D / 4) / NT;
+    static_assert(KT * (D / 4) % NT == 0, "staging items divide evenly over the block");
+    f32x4 pk[NSTG], pv[NSTG];
+    auto request = [&](const int j0) {
+#pragma unroll
+        for (int u = 0; u < NSTG; ++u) {
+            const int item = tid + u * NT;
+            const int key = min(j0 + item / (D / 4), T - 1), c4 = item % (D / 4);
+            const float* p = base + (size_t)key * C3;
+            pk[u] = *reinterpret_cast<const f32x4*>(p + koff + 4 * c4);
+            pv[u] = *reinterpret_cast<const f32x4*>(p + voff + 4 * c4);
+        }
+    };
+    request(0);
     for (int j0 = 0; j0 < T; j0 += KT) {
         __syncthreads();
         // ---- stage K (row-major, scaled) and V (transposed) tiles as fp16 hi/lo ----
-        for (int item = tid; item < KT * (D / 4); item += NT) {
+#pragma unroll
+        for (int u = 0; u < NSTG; ++u) {
+            const int item = tid + u * NT;
             const int key = item / (D / 4), c4 = item % (D / 4);
-            float4 kv = make_float4(0, 0, 0, 0), vv = make_float4(0, 0, 0, 0);
-            if (j0 + key < T) {
-                const float* p = base + (size_t)(j0 + key) * C3;
-                kv = *reinterpret_cast<const float4*>(p + koff + 4 * c4);
-                vv = *reinterpret_cast<const float4*>(p + voff + 4 * c4);
-            }
+            const bool in = j0 + key < T;
+            float4 kv = make_float4(in ? pk[u][0] : 0.f, in ? pk[u][1] : 0.f, in ? pk[u][2] : 0.f, in ? pk[u][3] : 0.f);
+            const float4 vv = make_float4(in ? pv[u][0] : 0.f, in ? pv[u][1] : 0.f, in ? pv[u][2] : 0.f, in ? pv[u][3] : 0.f);
             kv.x *= scale; kv.y *= scale; kv.z *= scale; kv.w *= scale;
             f16x4 hi, lo;
             split4(kv, hi, lo);
@@ -90,6 +106,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_attention_mfma(const float* __re
             }
         }
         __syncthreads();
+        if (j0 + KT < T) request(j0 + KT);
         const int nsub = (T - j0) >= KT ? 2 : ((T - j0) + 31) / 32;     // 32-key sub-tiles in this tile
         f32x16 sc[2];
         float mx = m;
