@@ -381,11 +381,11 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                 d[0] = ok ? v.x : 0.f; d[1] = ok ? v.y : 0.f; d[2] = ok ? v.z : 0.f; d[3] = ok ? v.w : 0.f;
             } else {
                 // fp16 hi/lo split: x = hi + lo + O(2^-22 |x|); both halves round-to-nearest; full split precision holds for
-                // 2e-3 <= |x| <= 4094.  Values are saturated at fp16's largest finite value instead of producing inf (|x| up to
-                // 1.3e5 then still splits exactly into hi + lo, beyond that the operand clips — raw residual-stream inputs are
-                // unbounded in principle).  The same clamp zeroes padding: its bound is 0 there (one select per item, and
-                // lo = 0 - 0 follows).
-                const float lim = ok ? 65504.f : 0.f;
+                // 2e-3 <= |x| <= 4094 (below: absolute error <= 2^-29).  A value beyond fp16's range is NOT clipped: its hi half
+                // becomes inf, lo = x - inf = -inf, and every output it reaches is NaN — the step epilogue raises the engine's
+                // sticky range flag on it and the host falls back to the exact-fp32 kernels (include/ccdm_hip.h).  The median
+                // below only zeroes padding: its bound is 0 there and infinite elsewhere (one select per item; lo = 0 - 0 follows).
+                const float lim = ok ? __builtin_inff() : 0.f;
                 v.x = __builtin_amdgcn_fmed3f(v.x, -lim, lim); v.y = __builtin_amdgcn_fmed3f(v.y, -lim, lim);
                 v.z = __builtin_amdgcn_fmed3f(v.z, -lim, lim); v.w = __builtin_amdgcn_fmed3f(v.w, -lim, lim);
                 f16x4 hi, lo;

@@ -109,15 +109,15 @@ extern "C" int ccdm_engine_set_epilogue(ccdm_engine* e, const ccdm_post_args* a)
 
 extern "C" int ccdm_engine_num_ops(const ccdm_engine* e) { return e ? (int)e->ops.size() : -1; }
 
-extern "C" int ccdm_engine_set_run(ccdm_engine* e, const float* noise, int64_t noise_step_stride, uint64_t philox_seed,
+extern "C" int ccdm_engine_set_run(ccdm_engine* e, const float* noise, int64_t noise_step_stride, int32_t noise_row0, uint64_t philox_seed,
                                    uint32_t sample_offset, float* out_probs, int64_t* out_onehot, float* posterior_out) {
     CCDM_REQUIRE(e && e->has_post, "engine_set_run: no epilogue set");
     ccdm_post_args& p = e->post;
-    const bool same = p.noise == noise && p.noise_step_stride == noise_step_stride && p.philox_seed == philox_seed &&
+    const bool same = p.noise == noise && p.noise_step_stride == noise_step_stride && p.noise_row0 == noise_row0 && p.philox_seed == philox_seed &&
                       p.sample_offset == sample_offset && p.out_probs == out_probs && p.out_onehot == out_onehot &&
                       p.posterior_out == posterior_out;
     if (!same) drop_graph(e);
-    p.noise = noise; p.noise_step_stride = noise_step_stride; p.philox_seed = philox_seed; p.sample_offset = sample_offset;
+    p.noise = noise; p.noise_step_stride = noise_step_stride; p.noise_row0 = noise_row0; p.philox_seed = philox_seed; p.sample_offset = sample_offset;
     p.out_probs = out_probs; p.out_onehot = out_onehot; p.posterior_out = posterior_out;
     return 0;
 }

@@ -50,6 +50,14 @@ __global__ __launch_bounds__(256) void k_posterior(const ccdm_post_args a) {
     const float* hp = a.head + i * a.head_stride;
 #pragma unroll
     for (int k = 0; k < KP; ++k) x0[k] = k < K ? hp[k] : -INFINITY;
+    if (a.range_flag) {
+        // a non-finite head value is how an F16X3 range overflow anywhere upstream surfaces (include/ccdm_hip.h): NaN/Inf
+        // survive every conv, GroupNorm and attention on the way here.  (The clamp below would hide it: fmaxf(NaN, 1e-12) = 1e-12.)
+        float chk = 0.f;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) if (k < K) chk += fabsf(x0[k]);
+        if (!(chk <= 3.0e38f)) *a.range_flag = 1;        // benign race: every writer stores the same value
+    }
     if (a.softmax) {
         float mx = x0[0];
 #pragma unroll
@@ -129,7 +137,7 @@ __global__ __launch_bounds__(256) void k_posterior(const ccdm_post_args a) {
         float best = -INFINITY;
         int bi = 0;
         if (a.noise) {
-            const float* e = a.noise + (size_t)step * a.noise_step_stride + i * K;
+            const float* e = a.noise + (size_t)(step - a.noise_row0) * a.noise_step_stride + i * K;
 #pragma unroll
             for (int k = 0; k < KP; ++k) {
                 if (k < K) {

@@ -270,6 +270,17 @@ class SamplerEngine:
             self._sd["out.2.weight"] = torch.cat([wk, torch.zeros((Kp - K,) + tuple(wk.shape[1:]))], 0)
             self._sd["out.2.bias"] = torch.cat([bk, torch.zeros(Kp - K)], 0)
         self.head = self._conv([h], "out.2", Kp, 3, gn="out.0", act=hip.ACT_SILU, stats=False)
+        # optional parallel head (unet.py:716-726,805-807): GN -> SiLU -> conv to K-1 logits, no softmax; evaluated on every
+        # U-Net call like the reference's forward does
+        self.head_ce: Optional[DevTensor] = None
+        if spec.ce_head:
+            Kc = K - 1
+            Kcp = (Kc + 3) // 4 * 4
+            if Kcp != Kc:
+                wk, bk = self._sd["out_ce.2.weight"], self._sd["out_ce.2.bias"]
+                self._sd["out_ce.2.weight"] = torch.cat([wk, torch.zeros((Kcp - Kc,) + tuple(wk.shape[1:]))], 0)
+                self._sd["out_ce.2.bias"] = torch.cat([bk, torch.zeros(Kcp - Kc)], 0)
+            self.head_ce = self._conv([h], "out_ce.2", Kcp, 3, gn="out_ce.0", act=hip.ACT_SILU, stats=False)
         self.n_unet_ops = lib.ccdm_engine_num_ops(self._handle)
 
         post = hip.PostArgs()
@@ -281,6 +292,8 @@ class SamplerEngine:
         post.xt_next = self.xt.data_ptr()
         post.xin, post.xin_stride = self.xin.ptr, self.Cs
         post.out_probs, post.out_onehot, post.posterior_out = self.out_probs.data_ptr(), self.out_onehot.data_ptr(), 0
+        self.flag = self._dev((1,), torch.int32, zero=True)      # sticky: a head output was not finite (F16X3 range overflow upstream)
+        post.noise_row0, post.range_flag = 0, self.flag.data_ptr()
         self._post = post
         hip.check(lib.ccdm_engine_set_epilogue(self._handle, C.byref(post)), "engine_set_epilogue")
         self._sd = None   # host copies no longer needed
@@ -357,20 +370,36 @@ class SamplerEngine:
         self._tables_key = key
 
     def run(self, n_steps: int, *, noise: Optional[torch.Tensor] = None, philox_seed: int = 0, sample_offset: int = 0,
-            with_epilogue: bool = True, use_graph: bool = False, first_row: int = 0,
+            with_epilogue: bool = True, use_graph: bool = False, first_row: int = 0, noise_row0: int = 0,
             posterior_out: Optional[torch.Tensor] = None) -> None:
-        """Launch n_steps denoise steps (asynchronous on the current torch stream)."""
+        """Launch n_steps denoise steps starting at table row `first_row` (asynchronous on the engine's stream).
+        noise: [rows, N*H*W*K] host-drawn Exp(1), row r belonging to step row noise_row0 + r."""
         npn = self.N * self.H * self.W * self.K
         if noise is not None:
             assert noise.is_cuda and noise.dtype == torch.float32 and noise.is_contiguous()
-            assert noise.numel() >= max(first_row + n_steps - 1, 1) * npn, "noise tensor too small"
+            assert first_row >= noise_row0 and noise.numel() >= max(first_row - noise_row0 + n_steps - 1, 1) * npn, "noise tensor too small"
             self._noise_keepalive = noise
         hip.check(self.lib.ccdm_engine_set_run(
-            self._handle, noise.data_ptr() if noise is not None else 0, npn, int(philox_seed) & (2 ** 64 - 1),
+            self._handle, noise.data_ptr() if noise is not None else 0, npn, int(noise_row0), int(philox_seed) & (2 ** 64 - 1),
             int(sample_offset), self.out_probs.data_ptr(), self.out_onehot.data_ptr(),
             posterior_out.data_ptr() if posterior_out is not None else 0), "engine_set_run")
         hip.check(self.lib.ccdm_engine_run(self._handle, first_row, n_steps, int(with_epilogue), int(use_graph),
                                            self._stream()), "engine_run")
+
+    def ce_logits(self) -> Optional[torch.Tensor]:
+        """[N,K-1,H,W] logits of the optional ce head after the last run (BCHW view of channels-last memory), else None."""
+        if self.head_ce is None:
+            return None
+        return self.head_ce.buf[..., : self.K - 1].clone().permute(0, 3, 1, 2)
+
+    def raise_if_flagged(self) -> None:
+        """Synchronises with the engine's stream.  Raises CcdmRangeError (and clears the flag) if any head output of the runs
+        since the last check was not finite."""
+        if int(self.flag.item()) != 0:
+            self.flag.zero_()
+            raise hip.CcdmRangeError(
+                "the network output is not finite" + (": a staged activation left the range of the fp16 split (|a| >= 4094, "
+                "include/ccdm_hip.h); re-run with prec=PREC_F32" if self.prec == hip.PREC_F16X3 else " (exact-fp32 kernels: check the weights and inputs)"))
 
     # timing taps for bench.py
     def profile_op(self, op_index: int, capacity: int = 4096) -> None:

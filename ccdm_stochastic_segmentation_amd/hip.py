@@ -22,6 +22,7 @@ ACT_NONE, ACT_SILU = 0, 1
 PREC_F32, PREC_F16X3 = 0, 1
 STEP_SAMPLE, STEP_LAST_CONFIDENCE, STEP_LAST_MAJORITY, STEP_LAST_KEEP, STEP_SOFTMAX_ONLY = 0, 1, 2, 3, 4
 STATS_MAX_SLICES = 16
+ABI_VERSION = 2          # CCDM_ABI_VERSION of include/ccdm_hip.h
 
 
 class ConvArgs(C.Structure):
@@ -58,6 +59,8 @@ class PostArgs(C.Structure):
         ("out_probs", C.c_void_p),
         ("out_onehot", C.c_void_p),
         ("posterior_out", C.c_void_p),
+        ("noise_row0", C.c_int32),
+        ("range_flag", C.c_void_p),
     ]
 
 
@@ -90,7 +93,7 @@ SIGNATURES = {
     "ccdm_engine_add_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ccdm_engine_set_epilogue": (C.c_int, [C.c_void_p, C.POINTER(PostArgs)]),
     "ccdm_engine_num_ops": (C.c_int, [C.c_void_p]),
-    "ccdm_engine_set_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ccdm_engine_set_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ccdm_engine_run": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ccdm_engine_profile_op": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "ccdm_engine_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -104,20 +107,47 @@ class CcdmHipError(RuntimeError):
     pass
 
 
+class CcdmRangeError(CcdmHipError):
+    """The network output of a run was not finite: with PREC_F16X3 the signature of a staged activation beyond the fp16
+    split's range (|a| >= 4094, include/ccdm_hip.h).  Outputs of that run are invalid."""
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile libccdm_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    """Compile libccdm_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).  One object per source,
+    compiled in parallel into <package>/build/ (only the sources that changed), then linked."""
+    from concurrent.futures import ThreadPoolExecutor
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "ccdm_common.h"), os.path.join(CSRC, "ccdm_conv_common.h"), os.path.join(ROOT, "include", "ccdm_hip.h")]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
-        return LIB_PATH
+    hdrs = [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".h")] + [os.path.join(ROOT, "include", "ccdm_hip.h")]
     extra = ["-DCCDM_ABLATION"] if os.environ.get("CCDM_ABLATION") else []      # tools/bench_conv.py ABLATE / TIMELINE modes
     extra += os.environ.get("CCDM_HIPCC_EXTRA", "").split()                     # experiments, e.g. -DCCDM_NT_STORES=1
-    cmd = ["hipcc", *HIPCC_FLAGS, *extra, "-I" + os.path.join(ROOT, "include"), *srcs, "-o", LIB_PATH]
+    objdir = os.path.join(_HERE, "build", "obj" + ("_" + str(abs(hash(tuple(extra))) % 10 ** 8) if extra else ""))
+    os.makedirs(objdir, exist_ok=True)
+    newest_hdr = max(os.path.getmtime(h) for h in hdrs)
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"]
+
+    def compile_one(src: str):
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), newest_hdr):
+            return obj, False
+        cmd = ["hipcc", *flags, *extra, "-I" + os.path.join(ROOT, "include"), "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise CcdmHipError("hipcc failed:\n" + r.stdout + r.stderr)
+        return obj, True
+
+    with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 1)) as ex:
+        res = list(ex.map(compile_one, srcs))
+    objs = [o for o, _ in res]
+    if not force and not any(c for _, c in res) and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(o) for o in objs):
+        return LIB_PATH
+    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
-        raise CcdmHipError("hipcc failed:\n" + r.stdout + r.stderr)
+        raise CcdmHipError("hipcc link failed:\n" + r.stdout + r.stderr)
     return LIB_PATH
 
 
@@ -143,6 +173,8 @@ def load() -> C.CDLL:
             raise CcdmHipError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
+    if lib.ccdm_version() != ABI_VERSION:
+        raise CcdmHipError(f"{LIB_PATH} implements ABI version {lib.ccdm_version()}, this host code needs {ABI_VERSION}: rebuild it")
     _lib = lib
     return lib
 

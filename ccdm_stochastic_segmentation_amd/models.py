@@ -250,11 +250,21 @@ class UNetModel(nn.Module):
         raise RuntimeError("UNetModel has no eager forward; call it through DenoisingModel (HIP engine)")
 
 
+# host-noise staging budget of rng="torch_cpu": the Exp(1) draws are made and uploaded in blocks of whole steps no larger
+# than this many bytes (the reference never holds more than one step of noise; one block of a few steps keeps the copies
+# large without O(T) memory on the host and the device)
+HOST_NOISE_BLOCK_BYTES = 256 << 20
+
+
 class DenoisingModel(nn.Module):
     """The sampler.  `rng` selects where the Exp(1) noise of the categorical draws comes from:
-    "torch_cpu" (default) — drawn on the host from torch's global CPU generator in exactly the order the
-      reference's CPU path consumes it (parity mode; the host RNG is the bottleneck);
-    "philox" — Philox4x32-10 inside the epilogue kernel (throughput mode; statistically identical)."""
+    "philox" (default) — Philox4x32-10 inside the epilogue kernel, keyed by (pixel, global sample index, step): the
+      throughput mode, statistically identical to the reference's draws;
+    "torch_cpu" — drawn on the host from torch's global CPU generator in exactly the order the reference's CPU path
+      consumes it (parity mode: seeded runs reproduce the reference's class indices; the host RNG is the bottleneck).
+    `prec` selects the conv arithmetic: hip.PREC_F16X3 (default; fp16 hi/lo split x3 on the matrix cores, ~2^-22 per
+    product, with the exact-fp32 kernel taking over any layer whose raw input leaves the split's range) or
+    hip.PREC_F32 (exact fp32 MFMA everywhere, the validation mode)."""
 
     def __init__(self, diffusion: DiffusionModel, unet: UNetModel, dataset_file: str, step_T_sample: str = "majority"):
         super().__init__()
@@ -262,13 +272,17 @@ class DenoisingModel(nn.Module):
         self.unet = unet
         self.dataset_file = dataset_file
         self.step_T_sample = step_T_sample
-        self.rng = "torch_cpu"
+        self.rng = "philox"
         self.philox_seed = 0
         self.sample_offset = 0          # global index of sample 0 when the batch is sharded over ranks
         self.noise_slice: Optional[Tuple[int, int]] = None   # (global_batch, first_sample) for torch_cpu sharding
         self.use_graph = False
         self.substreams = 1             # > 1: the batch is sampled as that many contiguous sub-batches on concurrent HIP streams
-        self.prec = hip.PREC_F32
+        self.prec = hip.PREC_F16X3
+        # what to do when a PREC_F16X3 run reports a range overflow (hip.CcdmRangeError): "f32" = repeat the call with the
+        # exact-fp32 kernels (same seeds, so the samples are the ones an all-fp32 run would have drawn) and log a warning;
+        # "raise" = propagate the error
+        self.on_range_error = "f32"
         self._engines: Dict[Any, Tuple[int, SamplerEngine]] = {}
 
     @property
@@ -291,32 +305,65 @@ class DenoisingModel(nn.Module):
         return self.forward_denoising(x, condition, feature_condition, cast(int, t.item()), label_ref_logits)
 
     # ------------------------------------------------------------------ engine plumbing
+    def _weights_key(self) -> Tuple[int, int]:
+        """Changes whenever the U-Net's parameters do: load_state_dict / .to() bump the explicit counter, in-place updates
+        (optimizer steps, Polyak averaging, p.data.copy_) bump the tensors' own version counters."""
+        return self.unet._weights_version, sum(int(p._version) for p in self.unet.parameters())
+
     def _engine(self, x: Tensor, condition: Tensor, feature_condition: Optional[Tensor], slot: int = 0) -> SamplerEngine:
         """The step executor for this input geometry (cached).  `slot` tells apart the engines of concurrent sub-batches."""
         N, K, H, W = x.shape
+        spec = self.unet.spec
+        if feature_condition is not None and spec.feature_condition_unwired:
+            # the reference concatenates at these blocks without having widened them and fails in the conv (unet.py:770-788)
+            raise RuntimeError(f"feature_condition given, but input block(s) {spec.feature_condition_unwired} were not widened for it "
+                               "(feature_cond_encoder target_layer / output_stride do not line up): channel mismatch")
         fshape = tuple(feature_condition.shape[1:]) if feature_condition is not None else None
-        if not self.unet.spec.feature_condition_idx:
-            fshape = None
+        if not spec.feature_condition_idx:
+            fshape = None                        # no injection point configured: the reference ignores the tensor too
         dev = next(self.unet.parameters()).device
         key = (N, H, W, int(condition.shape[1]), fshape, str(dev), self.prec, slot)
+        wkey = self._weights_key()
         hit = self._engines.get(key)
-        if hit is not None and hit[0] == self.unet._weights_version:
+        if hit is not None and hit[0] == wkey:
             return hit[1]
-        eng = SamplerEngine(self.unet.spec, self.unet.state_dict(), N, H, W, K, int(condition.shape[1]), dev,
+        eng = SamplerEngine(spec, self.unet.state_dict(), N, H, W, K, int(condition.shape[1]), dev,
                             max_steps=self.time_steps, feature_shape=fshape, prec=self.prec)
-        self._engines = {k: v for k, v in self._engines.items() if v[0] == self.unet._weights_version}
-        self._engines[key] = (self.unet._weights_version, eng)
+        self._engines = {k: v for k, v in self._engines.items() if v[0] == wkey}
+        self._engines[key] = (wkey, eng)
         return eng
 
     @staticmethod
     def _to_index(x: Tensor, device) -> Tensor:
         return x.argmax(dim=1).to(device=device, dtype=torch.uint8).contiguous()
 
+    def _with_range_fallback(self, fn):
+        state = torch.get_rng_state() if self.rng == "torch_cpu" else None
+        try:
+            return fn()
+        except hip.CcdmRangeError as e:
+            if self.prec == hip.PREC_F32 or self.on_range_error != "f32":
+                raise
+            LOGGER.warning("%s -- repeating this call with the exact-fp32 kernels", e)
+            if state is not None:
+                torch.set_rng_state(state)
+            prec, self.prec = self.prec, hip.PREC_F32
+            try:
+                return fn()
+            finally:
+                self.prec = prec
+
     def forward_step(self, x: Tensor, condition: Tensor, feature_condition: Tensor, t: Tensor) -> dict:
-        """One U-Net evaluation at per-sample timesteps `t` (diffusion_denoising.py:161-162 -> unet.py:744-808).
-        `x` must be one-hot (it is everywhere on this path)."""
-        if self.unet.spec.ce_head:
-            raise NotImplementedError("ce_head logits are not produced by the HIP path")
+        return self._with_range_fallback(lambda: self._forward_step(x, condition, feature_condition, t))
+
+    def forward_denoising(self, x: Optional[Tensor], condition: Tensor, feature_condition: Tensor,
+                          init_t: Optional[int] = None, label_ref_logits: Optional[Tensor] = None) -> dict:
+        return self._with_range_fallback(lambda: self._forward_denoising(x, condition, feature_condition, init_t, label_ref_logits))
+
+    def _forward_step(self, x: Tensor, condition: Tensor, feature_condition: Tensor, t: Tensor) -> dict:
+        """One U-Net evaluation at per-sample timesteps `t` (diffusion_denoising.py:161-162 -> unet.py:744-808): the
+        network's own output (probabilities, or logits with `softmax_output: no`) and, with `ce_head`, the extra head's
+        logits (unet.py:716-726,805-807).  `x` must be one-hot (it is everywhere on this path)."""
         eng = self._engine(x, condition, feature_condition)
         N = x.shape[0]
         tt = t.detach().float().reshape(-1).cpu()
@@ -327,11 +374,13 @@ class DenoisingModel(nn.Module):
             eng.set_tables([float(v) for v in tt], [(0.0, 1.0, hip.STEP_SOFTMAX_ONLY)] * N, per_sample=True)
             eng.run(1, with_epilogue=True, use_graph=False)
             out = eng.out_probs.clone().permute(0, 3, 1, 2)
+            logits = eng.ce_logits()
         eng.leave()
-        return {"diffusion_out": out, "logits": None}
+        eng.raise_if_flagged()
+        return {"diffusion_out": out, "logits": logits}
 
-    def forward_denoising(self, x: Optional[Tensor], condition: Tensor, feature_condition: Tensor,
-                          init_t: Optional[int] = None, label_ref_logits: Optional[Tensor] = None) -> dict:
+    def _forward_denoising(self, x: Optional[Tensor], condition: Tensor, feature_condition: Tensor,
+                           init_t: Optional[int] = None, label_ref_logits: Optional[Tensor] = None) -> dict:
         if label_ref_logits is not None:
             # the reference's guidance branch reads attributes that do not exist (guidance_scale_weights,
             # diffusion_denoising.py:172-174): it raises AttributeError there too.
@@ -347,17 +396,10 @@ class DenoisingModel(nn.Module):
         for t in t_values:
             a, c = self.diffusion.posterior_coeffs(t)
             coeffs.append((a, c, hip.STEP_SAMPLE if t > 1 else last_mode))
-        host_noise = None
-        if self.rng == "torch_cpu":
-            n_draws = sum(1 for t in t_values if t > 1)
-            if n_draws:
-                gN, first = self.noise_slice if self.noise_slice is not None else (N, 0)
-                host = torch.empty((n_draws, gN, H * W * K), dtype=torch.float32)
-                for j in range(n_draws):        # one [gN*H*W, K] draw per step, like torch.multinomial
-                    host[j].view(-1).exponential_(1)
-                host_noise = host[:, first:first + N]
-        elif self.rng != "philox":
+        if self.rng not in ("philox", "torch_cpu"):
             raise ValueError(f"unknown rng mode {self.rng!r}")
+        host_rng = self.rng == "torch_cpu"
+        gN, first = self.noise_slice if (host_rng and self.noise_slice is not None) else (N, 0)
         # Samples are independent through all T steps: the batch may be walked as several contiguous
         # sub-batches, each with its own step executor on its own HIP stream.  The kernels of the low-resolution stages
         # fill a fraction of the GPU; two sub-batches half a step apart fill each other's gaps.  Nothing a sample sees
@@ -370,21 +412,39 @@ class DenoisingModel(nn.Module):
             lo, hi = bounds[j], bounds[j + 1]
             fc = feature_condition[lo:hi] if feature_condition is not None else None
             eng = self._engine(x[lo:hi], condition[lo:hi], fc, slot=j)
-            noise = host_noise[:, lo:hi].contiguous().to(eng.device) if host_noise is not None else None
             with eng.enter():
                 eng.set_inputs(self._to_index(x[lo:hi], eng.device), condition[lo:hi].to(eng.device), fc)
                 eng.set_tables([float(t) for t in t_values], coeffs)
-            parts.append((eng, noise, lo, hi))
-        if nsub == 1:
-            eng, noise, lo, hi = parts[0]
-            eng.run(S, noise=noise, philox_seed=self.philox_seed, sample_offset=self.sample_offset, use_graph=self.use_graph)
+            parts.append((eng, lo, hi))
+        # Step blocks.  Device RNG: one block.  Host RNG (parity mode): the Exp(1) noise is drawn from torch's CPU generator
+        # one [gN*H*W, K] block per sampling step — exactly the reference's consumption order, whatever the blocking — and
+        # uploaded a bounded number of steps at a time, so host and device hold O(block), not O(T), noise.
+        if host_rng:
+            per_step = gN * H * W * K * 4
+            blk = max(1, HOST_NOISE_BLOCK_BYTES // max(per_step, 1))
+            blocks = [(s0, min(s0 + blk, S)) for s0 in range(0, S, blk)]
         else:
-            for s in range(S):                   # one step of every sub-batch in turn: the streams advance side by side
-                for eng, noise, lo, hi in parts:
-                    eng.run(1, first_row=s, noise=noise, philox_seed=self.philox_seed, sample_offset=self.sample_offset + lo,
-                            use_graph=self.use_graph)
+            blocks = [(0, S)]
+        for s0, s1 in blocks:
+            noises: List[Optional[Tensor]] = [None] * nsub
+            if host_rng:
+                host = torch.empty((s1 - s0, gN, H * W * K), dtype=torch.float32)
+                for j in range(s0, s1):             # one draw per step with t > 1, like torch.multinomial; the last step draws nothing
+                    if t_values[j] > 1:
+                        host[j - s0].view(-1).exponential_(1)
+                for j, (eng, lo, hi) in enumerate(parts):
+                    with torch.cuda.stream(eng.stream):
+                        noises[j] = host[:, first + lo:first + hi].contiguous().to(eng.device)
+            if nsub == 1:
+                parts[0][0].run(s1 - s0, first_row=s0, noise=noises[0], noise_row0=s0, philox_seed=self.philox_seed,
+                                sample_offset=self.sample_offset, use_graph=self.use_graph)
+            else:
+                for s in range(s0, s1):              # one step of every sub-batch in turn: the streams advance side by side
+                    for j, (eng, lo, hi) in enumerate(parts):
+                        eng.run(1, first_row=s, noise=noises[j], noise_row0=s0, philox_seed=self.philox_seed,
+                                sample_offset=self.sample_offset + lo, use_graph=self.use_graph)
         outs = []
-        for eng, noise, lo, hi in parts:
+        for eng, lo, hi in parts:
             with eng.enter():
                 if t_values[-1] > 1 or last_mode == hip.STEP_LAST_KEEP:
                     idx = eng.xt.reshape(hi - lo, H, W).long()
@@ -395,6 +455,8 @@ class DenoisingModel(nn.Module):
                     out = eng.out_onehot.clone().permute(0, 3, 1, 2)
             eng.leave()
             outs.append(out)
+        for eng, lo, hi in parts:
+            eng.raise_if_flagged()
         out = outs[0] if nsub == 1 else torch.cat(outs, 0)
         if out.device != x.device:
             out = out.to(x.device)

@@ -77,6 +77,9 @@ class UNetSpec:
     output_blocks: List[List[object]] = field(default_factory=list)
     feature_condition_idx: List[int] = field(default_factory=list)   # input-block indices that get `cat([h, feat])`
     feature_channels: int = 0
+    # configured injection points whose block was NOT widened (target_layer / output_stride do not line up): the reference
+    # builds such a model but its forward fails on the channel mismatch as soon as a feature tensor is passed
+    feature_condition_unwired: List[int] = field(default_factory=list)
     softmax_output: bool = True
     ce_head: bool = False
     time_embed_dim: int = 0
@@ -289,6 +292,7 @@ def make_unet_spec(
             ob += 1
     spec.head_in = ch
     spec.feature_condition_idx = [i for i in fidx if i in widened]
+    spec.feature_condition_unwired = [i for i in fidx if i not in widened]
     spec.feature_channels = fch if spec.feature_condition_idx else 0
     for _, l in spec.all_layers():
         c = l.cin if l.kind == "res" else (l.ch if l.kind == "attn" else None)

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define CCDM_ABI_VERSION 1
+#define CCDM_ABI_VERSION 2
 #define CCDM_MAX_CHANNELS 1024      /* max C0+C1 of a GroupNorm'ed conv input */
 #define CCDM_STATS_MAX_SLICES 16    /* partial-statistics slices per sample */
 
@@ -49,6 +49,10 @@ int ccdm_gn_stats(const float* x /*dev [N,HW,C]*/, int N, int HW, int C, int sli
 enum { CCDM_ACT_NONE = 0, CCDM_ACT_SILU = 1 };
 enum { CCDM_PREC_F32 = 0,      /* v_mfma_f32_32x32x2_f32: exact fp32 products and accumulation          */
        CCDM_PREC_F16X3 = 1 };  /* fp16 hi/lo split, 3 x v_mfma_f32_32x32x16_f16, fp32 accumulate (~2^-22) */
+/* Range of CCDM_PREC_F16X3: a staged activation a (after GroupNorm/SiLU, or the raw input where there is none) must satisfy
+ * |a| < 4094.  Beyond that its fp16 hi half is infinite and every output the element reaches is NaN/Inf — never a silently
+ * clipped number; the step epilogue (ccdm_post_args.range_flag) turns that into a sticky device flag the host checks.
+ * Below |a| ~ 2e-3 the split keeps an ABSOLUTE error <= 2^-29 (fp16 subnormal spacing after the 2^4 pre-scale). */
 
 typedef struct ccdm_conv_args {
     /* input: virtual channel concat [in0 | in1] (in1 may be NULL); both [N,Hin,Win,C*] */
@@ -135,7 +139,7 @@ typedef struct ccdm_post_args {
     /* per-step coefficients: row = *step_ptr (0 if NULL) of step_table = {alpha_t, cumalpha_tm1, mode, 0} */
     const float* step_table; const int32_t* step_ptr;
     /* noise */
-    const float* noise; int64_t noise_step_stride;        /* dev or NULL -> Philox */
+    const float* noise; int64_t noise_step_stride;        /* dev or NULL -> Philox; row r of the buffer is step row noise_row0 + r */
     uint64_t philox_seed; uint32_t sample_offset;         /* global index of sample 0 (batch sharding) */
     /* outputs */
     uint8_t* xt_next;            /* dev [N,HW] (may alias xt) */
@@ -143,6 +147,9 @@ typedef struct ccdm_post_args {
     float* out_probs;            /* dev [N,HW,K] fp32   (confidence) or NULL */
     int64_t* out_onehot;         /* dev [N,HW,K] int64  (majority)   or NULL */
     float* posterior_out;        /* dev [N,HW,K] optional debug/teacher-forcing tap of P^ , or NULL */
+    int32_t noise_row0;          /* step row the first row of `noise` belongs to (host noise uploaded in blocks of steps) */
+    int32_t* range_flag;         /* dev scalar or NULL: set to 1 (sticky, never cleared by the kernel) when the head output of
+                                    any pixel is not finite — the signature of an F16X3 range overflow upstream (see above) */
 } ccdm_post_args;
 
 int ccdm_posterior_sample(const ccdm_post_args* a, void* stream);
@@ -211,7 +218,7 @@ int ccdm_engine_add_attention(ccdm_engine* e, const float* qkv, float* out, int 
 int ccdm_engine_set_epilogue(ccdm_engine* e, const ccdm_post_args* a);      /* run after the ops of each step */
 int ccdm_engine_num_ops(const ccdm_engine* e);
 /* per-run mutable fields of the epilogue (everything else is fixed at build time) */
-int ccdm_engine_set_run(ccdm_engine* e, const float* noise, int64_t noise_step_stride,
+int ccdm_engine_set_run(ccdm_engine* e, const float* noise, int64_t noise_step_stride, int32_t noise_row0,
                         uint64_t philox_seed, uint32_t sample_offset,
                         float* out_probs, int64_t* out_onehot, float* posterior_out);
 /* run `n_steps` denoise steps starting at table row `first_row`; use_graph: 0 eager launches, 1 HIP graph of one step */

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(hip.SIGNATURES), declared ^ set(hip.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ccdm_version() == 1
+    assert lib.ccdm_version() == hip.ABI_VERSION == 2
     assert ctypes.sizeof(hip.ConvArgs) % 8 == 0 and ctypes.sizeof(hip.PostArgs) % 8 == 0
 
 
@@ -50,8 +50,9 @@ def test_struct_layout_matches_header():
       printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(ccdm_conv_args), offsetof(ccdm_conv_args, gamma), offsetof(ccdm_conv_args, w),
              offsetof(ccdm_conv_args, emb_row_of_sample), offsetof(ccdm_conv_args, out), offsetof(ccdm_conv_args, out_slices),
              offsetof(ccdm_conv_args, SC1), offsetof(ccdm_conv_args, skip_w));
-      printf("%zu %zu %zu %zu %zu\n", sizeof(ccdm_post_args), offsetof(ccdm_post_args, step_table), offsetof(ccdm_post_args, philox_seed),
-             offsetof(ccdm_post_args, xin_stride), offsetof(ccdm_post_args, posterior_out));
+      printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(ccdm_post_args), offsetof(ccdm_post_args, step_table), offsetof(ccdm_post_args, philox_seed),
+             offsetof(ccdm_post_args, xin_stride), offsetof(ccdm_post_args, posterior_out), offsetof(ccdm_post_args, noise_row0),
+             offsetof(ccdm_post_args, range_flag));
       return 0; }'''
     import tempfile
     with tempfile.TemporaryDirectory() as d:
@@ -61,7 +62,8 @@ def test_struct_layout_matches_header():
     A, B = hip.ConvArgs, hip.PostArgs
     mine = [ctypes.sizeof(A), A.gamma.offset, A.w.offset, A.emb_row_of_sample.offset, A.out.offset, A.out_slices.offset,
             A.SC1.offset, A.skip_w.offset,
-            ctypes.sizeof(B), B.step_table.offset, B.philox_seed.offset, B.xin_stride.offset, B.posterior_out.offset]
+            ctypes.sizeof(B), B.step_table.offset, B.philox_seed.offset, B.xin_stride.offset, B.posterior_out.offset,
+            B.noise_row0.offset, B.range_flag.offset]
     assert [int(v) for v in out] == mine
 
 
