@@ -1,17 +1,19 @@
 #!/usr/bin/env python3
 """Headline benchmark: categorical reverse-diffusion sampling throughput (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config c2|c3shard|c4|c4b64|c5shard]
 
-One "step" = one full pass of the hot path over one batch: the complete T=250-step sampling of a batch of
-64 LIDC-shaped samples per GPU (BASELINE config C2: 128x128, 2 classes, base-32 U-Net, synthetic image and
-random-init weights), including the per-step posterior + categorical draw (device Philox RNG) and, for
-N > 1, the final RCCL all_gather of the predictions.  Inputs are resident in HBM when timing starts.
-Prints ONE JSON line on rank 0.
+One "step" = one full pass of the hot path over one batch: the complete T-step sampling of one per-GPU batch
+(default BASELINE config C2: 64 LIDC-shaped samples, 128x128, 2 classes, T=250, base-32 U-Net, synthetic image,
+random-init weights), including the per-step posterior + categorical draw (device Philox RNG) and, for N > 1, the
+final RCCL all_gather of the predictions.  Inputs are resident in HBM when timing starts.  Prints ONE JSON line on
+rank 0.  With --gpus N > 1 and no launcher environment the script starts its own ranks
+(torch.distributed.run, one process per GPU, 127.0.0.1 rendezvous).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -21,52 +23,106 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-PER_GPU_BATCH = 64
-T_STEPS = 250
-H = W = 128
-K = 2
 LIDC_BP = dict(base_channels=32, channel_mult=None, attention_resolutions=[32, 16, 8], num_heads=1,
                num_head_channels=32, softmax_output=True)
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-# SURVEY §8(d), LIDC cfg, fp32, per sample per denoise step
-ALGO_MB_PER_SAMPLE_STEP = 163.1
-ALGO_WEIGHTS_MB = 4.82
+DINO_FCE = dict(type="dino", model="dino_vits8", channels=384, conditioning="concat_pixels_concat_features", output_stride=8,
+                scale="single", train=False, source_layer=11, target_layer=10)
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s is what a streaming copy reaches)
+MFMA_PEAK_TFLOPS = 2500.0        # dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
+# measured in the build container (profiles/r01_reference_vs_oracle_cpu.json): the oracle takes 1.148x the REAL reference's
+# time per denoise step on the same inputs, outputs bit-identical — the reported cpu_baseline is conservative by that factor
+ORACLE_OVER_REFERENCE_TIME = 1.148
+
+# Workloads (BASELINE.json configs; algorithmic figures per sample per denoise step from SURVEY 8(d) / BASELINE.md §4)
+CONFIGS = {
+    "c2": dict(title="C2: LIDCv1-shaped 128x128, 2 classes, T=250 cosine, base-32 U-Net (5.70 M params)", H=128, W=128, K=2, C_img=1, T=250,
+               batch=64, bp=LIDC_BP, fce=None, algo_mb=163.1, weights_mb=4.82, epilogue_mb=0.52, gflop=8.44, attn_gflop=0.138, image="uniform"),
+    "c3shard": dict(title="C3 per-GPU shard: LIDCv1-shaped 128x128, 2 classes, T=1000 cosine, 4 images x 16 samples", H=128, W=128, K=2, C_img=1,
+                    T=1000, batch=64, bp=LIDC_BP, fce=None, algo_mb=163.1, weights_mb=4.82, epilogue_mb=0.52, gflop=8.44, attn_gflop=0.138,
+                    image="uniform"),
+    "c4": dict(title="C4: Cityscapes-shaped 256x512, 20 classes, T=250, DINO feature concat [384,32,64], base-32 U-Net (7.80 M params)", H=256, W=512,
+               K=20, C_img=3, T=250, batch=16, bp=LIDC_BP, fce=DINO_FCE, algo_mb=1306.9, weights_mb=13.25, epilogue_mb=41.9, gflop=72.7,
+               attn_gflop=6.09, image="normal"),
+    "c4b64": dict(title="C4 at base 64: Cityscapes-shaped 256x512, 20 classes, T=250, DINO feature concat, base-64 U-Net (30.6 M params)", H=256, W=512,
+                  K=20, C_img=3, T=250, batch=16, bp=dict(LIDC_BP, base_channels=64), fce=DINO_FCE, algo_mb=2581.8, weights_mb=52.0,
+                  epilogue_mb=41.9, gflop=270.2, attn_gflop=12.2, image="normal"),
+    "c5shard": dict(title="C5 per-GPU shard: Cityscapes-shaped 512x1024, 20 classes, T=250, base-64 7-level U-Net (29.3 M params), attention over 8192 tokens",
+                    H=512, W=1024, K=20, C_img=3, T=250, batch=4, bp=dict(LIDC_BP, base_channels=64), fce=None, algo_mb=6502.1, weights_mb=102.5,
+                    epilogue_mb=167.8, gflop=625.5, attn_gflop=183.9, image="normal"),
+}
 
 
-def dominant_kernel_bytes(n: int) -> dict:
-    """Algorithmic bytes of ONE launch of the dominant kernel: ResBlock conv3x3 32->32 @128x128 with
-    GroupNorm+SiLU on load (8 launches per denoise step, 29.6 % of all FLOPs).
-    SURVEY §8(d): conv io 4*(Cin*h*w + Cout*h*w) + the GroupNorm's statistics read 4*C*h*w per sample,
-    + weights once per launch."""
-    conv_io = 4 * (32 + 32) * H * W * n
-    gn_read = 4 * 32 * H * W * n
-    weights = 4 * 9 * 32 * 32
-    return {"conv_io": conv_io, "gn_read": gn_read, "weights": weights, "total": conv_io + gn_read + weights}
+def cpu_model_name() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
-def cpu_baseline(sd, image4, seed=0):
+def cpu_baseline(sd, image4, cfg, seed=0):
     """Oracle (CPU restatement of the reference, torch-CPU fp32) on a bounded sample of the same workload:
-    N=4, the first 8 of 250 denoise steps, extrapolated x250/8."""
+    N=4, the first few of T denoise steps (about 15 s of CPU work), extrapolated to T."""
     from oracle import ccdm_oracle as O
     # more threads than ~16 makes torch-CPU slower on these small convs (256-core host: 85 s per step)
     torch.set_num_threads(min(os.cpu_count() or 1, 16))
-    sched = O.make_schedule("cosine", T_STEPS, {"s": 0.008})
+    T, K, H, W = cfg["T"], cfg["K"], cfg["H"], cfg["W"]
+    sched = O.make_schedule("cosine", T, {"s": 0.008})
     torch.manual_seed(seed)
     idx, _ = O.draw_x_T(4, K, H, W)
     x = O.one_hot_bchw(idx, K)
-    cfg = dict(num_heads=1, num_head_channels=32)
+    ocfg = dict(num_heads=1, num_head_channels=32)
     t0 = time.perf_counter()
-    O.forward_denoising(sd, cfg, sched, x, image4, None, 1, "confidence")            # warm-up: 1 step
+    O.forward_denoising(sd, ocfg, sched, x, image4, None, 1, "confidence")            # warm-up: 1 step
     warm = time.perf_counter() - t0
-    # bounded sample: ~15 s of CPU work (first step includes one-time warm-up, so this over-estimates the step time a bit)
-    n_steps = int(max(2, min(T_STEPS, 15.0 / max(warm, 1e-3))))
+    n_steps = int(max(2, min(T, 15.0 / max(warm, 1e-3))))
     t0 = time.perf_counter()
-    O.forward_denoising(sd, cfg, sched, x, image4, None, n_steps, "confidence")
+    O.forward_denoising(sd, ocfg, sched, x, image4, None, n_steps, "confidence")
     dt = time.perf_counter() - t0
     ms_step = dt / n_steps * 1e3
-    return {"value": 4.0 / (ms_step * 1e-3 * T_STEPS), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle (torch-CPU fp32, {torch.get_num_threads()} threads) N=4, {n_steps} of {T_STEPS} denoise steps timed ({dt:.1f} s), extrapolated x{T_STEPS}/{n_steps}",
-            "ms_per_denoise_step_n4": ms_step}
+    v = 4.0 / (ms_step * 1e-3 * T)
+    return {"value": v, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle (torch-CPU fp32, {torch.get_num_threads()} threads) N=4, {n_steps} of {T} denoise steps timed ({dt:.1f} s), extrapolated x{T}/{n_steps}",
+            "ms_per_denoise_step_n4": ms_step, "host_cpu": cpu_model_name(), "host_logical_cpus": os.cpu_count(),
+            "oracle_over_reference_time": ORACLE_OVER_REFERENCE_TIME,
+            "value_reference_equivalent": v * ORACLE_OVER_REFERENCE_TIME,
+            "note": "the oracle is 14.8 % slower than the real reference on identical inputs (build-container measurement, outputs bit-identical): "
+                    "value_reference_equivalent is the estimate for the reference itself on this host"}
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script with torch.distributed.run."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # the host driver supports dmabuf IPC only (RCCL needs it)
+    env["CCDM_BENCH_CHILD"] = "1"
+    return subprocess.call(cmd, env=env)
+
+
+def op_roofline(info, n, mean_ms, prec_f16x3):
+    """roofline object of one tapped launch: algorithmic bytes of op `info` at n samples over its mean duration."""
+    conv_io, gn, wts = info["io_bytes"] * n, info["gn_read_bytes"] * n, info["weight_bytes"]
+    total = conv_io + gn + wts
+    ach = total / (mean_ms * 1e-3) / 1e9
+    flop = info["flop"] * n
+    r = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+         "avg_launch_ms": mean_ms, "algorithmic_bytes_per_launch": total, "samples_per_launch": n,
+         "achieved_conv_io_only": (conv_io + wts) / (mean_ms * 1e-3) / 1e9,
+         "frac_conv_io_only": (conv_io + wts) / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+         "algorithmic_tflops": flop / (mean_ms * 1e-3) / 1e12,
+         # matrix-pipe utilisation from the instruction count: every fp32 product is 3 fp16 MFMA products (hi*hi, hi*lo, lo*hi),
+         # so the matrix cores execute 3x the algorithmic FLOPs; relative to the dense fp16 peak at the 2.4 GHz top clock
+         # (the PMC figure SQ_VALU_MFMA_BUSY_CYCLES / total SIMD cycles is in profiles/)
+         "mfma_util": (3.0 if prec_f16x3 else 16.0) * flop / (mean_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
+         "mfma_util_source": "analytic: MFMA FLOPs issued (3 fp16 products per fp32 product) / HIP-event duration / 2.5 PFLOP/s dense"}
+    return r
 
 
 def main():
@@ -74,9 +130,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2",
+                    help="workload (BASELINE.json configs); the headline metric is quoted on c2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the untimed extras (per-stage table, --substreams 2 figure)")
     ap.add_argument("--graph", type=int, default=0, help="1: replay each denoise step as a HIP graph (no kernel taps)")
-    ap.add_argument("--batch", type=int, default=PER_GPU_BATCH)
+    ap.add_argument("--batch", type=int, default=0, help="samples per GPU (default: the config's)")
+    ap.add_argument("--denoise-steps", type=int, default=0, help="strided walk of this many denoise steps instead of the full T (diagnostics; not the metric)")
     ap.add_argument("--substreams", type=int, default=1,
                     help="sample the per-GPU batch as this many contiguous sub-batches on concurrent HIP streams (results are bit-identical)")
     ap.add_argument("--rng", choices=["philox", "torch_cpu"], default="philox",
@@ -84,9 +144,13 @@ def main():
                          "on the host in the reference's order and copied over PCIe (host-RNG bound; reported for DESIGN.md, never the headline)")
     ap.add_argument("--prec", choices=["f32", "f16x3"], default="f16x3",
                     help="conv arithmetic: exact fp32 MFMA, or fp16 hi/lo split x3 MFMA with fp32 accumulate (~2^-22)")
+    ap.add_argument("--per-op", default="", help="write the per-op table of one extra tapped pass to this file (JSON)")
     args = ap.parse_args()
 
-    from ccdm_stochastic_segmentation_amd import build_model, make_synthetic_state_dict
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        raise SystemExit(self_launch(args))
+
+    from ccdm_stochastic_segmentation_amd import build_model, make_synthetic_state_dict, hip
     from ccdm_stochastic_segmentation_amd.distributed import init_from_env, all_gather_ragged
     import torch.distributed as dist
 
@@ -96,27 +160,37 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    n = args.batch
+    cfg = CONFIGS[args.config]
+    n = args.batch or cfg["batch"]
+    H, W, K, T, C_img = cfg["H"], cfg["W"], cfg["K"], cfg["T"], cfg["C_img"]
 
-    model = build_model(T_STEPS, "cosine", {"s": 0.008}, [(1, H, W), (K, H, W)], (1, H, W), "unet_openai", LIDC_BP,
-                        "datasets.lidc", "confidence", None)
+    model = build_model(T, "cosine", {"s": 0.008}, [(C_img, H, W), (K, H, W)], (C_img, H, W), "unet_openai", cfg["bp"],
+                        "datasets.lidc" if K == 2 else "datasets.cityscapes", "confidence", cfg["fce"])
     sd = {k: torch.from_numpy(v) for k, v in make_synthetic_state_dict(model.unet.spec, 0).items()}
     model.unet.load_state_dict(sd, strict=True)
     model = model.to(dev).eval()
-    from ccdm_stochastic_segmentation_amd import hip
-    model.prec = hip.PREC_F32 if args.prec == "f32" else hip.PREC_F16X3
+    f16 = args.prec == "f16x3"
+    model.prec = hip.PREC_F16X3 if f16 else hip.PREC_F32
     model.rng, model.philox_seed, model.use_graph = args.rng, 2024, bool(args.graph)
     model.sample_offset = rank * n                                # Philox counters keyed by global sample index
     model.substreams = args.substreams
 
     rng = np.random.default_rng(1234)
-    image_all = rng.uniform(-1, 1, (max(n, 4), 1, H, W)).astype(np.float32)
+    if cfg["image"] == "uniform":
+        image_all = rng.uniform(-1, 1, (max(n, 4), C_img, H, W)).astype(np.float32)
+    else:
+        image_all = rng.standard_normal((max(n, 4), C_img, H, W)).astype(np.float32)
     image = torch.from_numpy(image_all[:n]).to(dev)
+    feat = None
+    if cfg["fce"] is not None:
+        feat = torch.from_numpy(rng.standard_normal((n, 384, H // 8, W // 8)).astype(np.float32)).to(dev)
     x = torch.nn.functional.one_hot(torch.from_numpy(np.random.default_rng(42 + rank).integers(0, K, (n, H, W))), K)
     x = x.permute(0, 3, 1, 2).float().to(dev)
+    t_arg = {} if not args.denoise_steps else {"t": torch.as_tensor(10000 + args.denoise_steps)}
+    n_dsteps = args.denoise_steps or T
 
     def one_pass():
-        out = model(x, image)["diffusion_out"]
+        out = model(x, image, feat, **t_arg)["diffusion_out"]
         if world > 1:
             out = all_gather_ragged(out.contiguous(), n * world, world)     # the path's only collective
         return out
@@ -124,23 +198,39 @@ def main():
     for _ in range(args.warmup):
         one_pass()
     # the executor of sub-batch 0 (the whole batch when substreams == 1) carries the HIP-event taps
-    n_tap = n // max(1, min(args.substreams, n))
-    eng = model._engine(x[:n_tap], image[:n_tap], None, slot=0)
-    dom = next(i for i, nm in enumerate(eng.op_names) if nm == "input_blocks.1.0.in_layers.2")
+    nsub = max(1, min(args.substreams, n))
+    n_tap = n // nsub
+    eng = model._engine(x[:n_tap], image[:n_tap], feat[:n_tap] if feat is not None else None, slot=0)
+    conv_ops = [i for i, o in enumerate(eng.op_info) if o["kind"] == "conv" and o["k"] == 3 and o["gn"]]
+    # dominant shape = the (cin, cout, size) group of GN+SiLU 3x3 convs with the largest FLOP share of the step (C2: the eight
+    # 32->32 @128x128 launches, 29.6 %); heaviest = the single longest launch by algorithmic bytes (C2: decoder 64->32 @128x128)
+    groups = {}
+    for i in conv_ops:
+        o = eng.op_info[i]
+        if not o["skip"]:
+            groups.setdefault((o["cin"], o["cout"], o["hout"], o["wout"], o["stride"], o["up"]), []).append(i)
+    dom_key = max(groups, key=lambda k_: sum(eng.op_info[i]["flop"] for i in groups[k_]))
+    dom = groups[dom_key][0]
+    heavy = max(conv_ops, key=lambda i: eng.op_info[i]["io_bytes"] + eng.op_info[i]["gn_read_bytes"])
+    attn_ops = [i for i, o in enumerate(eng.op_info) if o["kind"] == "attention" and o["T"] >= 2048]
+    attn = max(attn_ops, key=lambda i: eng.op_info[i]["T"]) if attn_ops else None
     taps = not args.graph
+    tapped = [i for i in dict.fromkeys([dom, heavy, attn]) if i is not None]
     if taps:
-        eng.profile_op(dom, capacity=min(T_STEPS, 256))          # HIP events around that launch, on the engine's stream
+        for i in tapped:
+            eng.profile_op(i, capacity=n_dsteps)          # HIP events around that launch, on the engine's stream
 
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    kern = []
+    kern = {i: [] for i in tapped}
     for _ in range(args.steps):
         out = one_pass()
         if taps:
             torch.cuda.synchronize()
-            kern.append(eng.profile_read())
+            for i in tapped:
+                kern[i].append(eng.profile_read(i))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -150,48 +240,106 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert torch.isfinite(out).all()
+    if taps:
+        eng.profile_op(-1)
 
+    def mean_ms(i):
+        cnt = sum(k_[0] for k_ in kern[i])
+        return (sum(k_[0] * k_[1] for k_ in kern[i]) / cnt, cnt) if cnt else (0.0, 0)
+
+    res = None
     if rank == 0:
         total = n * world * args.steps
         ms_pass = dt / max(args.steps, 1) * 1e3
-        ms_dstep = ms_pass / T_STEPS
+        ms_dstep = ms_pass / n_dsteps
         res = {
-            "metric": "segmentation samples/sec, LIDC 128x128 T=250", "value": total / dt, "unit": "samples/s",
+            "metric": f"segmentation samples/sec, {'LIDC 128x128' if K == 2 else f'Cityscapes {H}x{W}'} T={T}", "value": total / dt, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_pass,
             "ms_per_denoise_step": ms_dstep, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.prec == "f32" else "f32 (conv products as split fp16 hi/lo x3 on MFMA, fp32 accumulate)", "data": "synthetic",
-            "config": {"workload": "C2: LIDCv1-shaped 128x128, 2 classes, T=250 cosine, base-32 U-Net (5.70 M params), "
-                                   f"batch={n} per GPU, {'device Philox RNG' if args.rng == 'philox' else 'host torch-CPU Exp(1) noise over PCIe (parity mode)'}, random-init weights",
-                       "global_batch": n * world, "time_steps": T_STEPS, "parallelism": f"batch-shard x{world}",
-                       "launch": "hip-graph" if args.graph else "eager", "substreams": max(1, min(args.substreams, n))},
+            "dtype": "f32" if not f16 else "f32 (conv products as split fp16 hi/lo x3 on MFMA, fp32 accumulate)", "data": "synthetic",
+            "config": {"workload": f"{cfg['title']}, batch={n} per GPU, "
+                                   f"{'device Philox RNG' if args.rng == 'philox' else 'host torch-CPU Exp(1) noise over PCIe (parity mode)'}, random-init weights",
+                       "name": args.config, "global_batch": n * world, "time_steps": T, "denoise_steps_run": n_dsteps,
+                       "parallelism": f"batch-shard x{world}", "launch": "hip-graph" if args.graph else "eager", "substreams": nsub},
         }
-        step_bytes = (ALGO_MB_PER_SAMPLE_STEP * n + ALGO_WEIGHTS_MB) * 1e6
-        res["roofline_step"] = {"bound": "hbm", "achieved": step_bytes / (ms_dstep * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": step_bytes / (ms_dstep * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                "note": "whole denoise step per GPU: SURVEY 8(d) 163.1 MB/sample + 4.82 MB weights, over ms_per_denoise_step"}
-        if taps and kern and kern[0][0] > 0:
-            cnt = sum(k[0] for k in kern)
-            mean_ms = sum(k[0] * k[1] for k in kern) / cnt
-            b = dominant_kernel_bytes(n_tap)
-            ach = b["total"] / (mean_ms * 1e-3) / 1e9
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_dominant_kernel.json")
-            if os.path.exists(pmc) and args.prec == "f16x3":
-                # HBM bytes per launch of this kernel from the committed rocprofv3 --pmc passes (tools/pmc_conv.sh;
-                # FETCH_SIZE x2 + WRITE_SIZE, KiB, per MI355X_MICROARCH.md) — collected off-line on the same shape at 64
-                # samples per launch; every byte of it is per-sample work, so a launch over n_tap samples moves n_tap/64 of it
-                traffic = json.load(open(pmc)).get("hbm_bytes") * n_tap / PER_GPU_BATCH
-            res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                               "traffic": traffic, "kernel": ("ccdm::k_conv<1, 16, 3, 1, 8, 32, 4, 2, 1, 1>" if args.prec == "f16x3" else "ccdm::k_conv<0, 32, 3, 1, 8, 32, 4, 2, 1, 1>")
-                                         + " = <PREC,CK,KS,STRIDE,TH,TW,WAVES,MI,NI,KSP>, engine op 1 (" + eng.op_names[dom] + ": conv3x3 32->32 @128x128, GN+SiLU on load)",
-                               "avg_launch_ms": mean_ms, "launches_timed": cnt, "algorithmic_bytes_per_launch": b["total"],
-                               "samples_per_launch": n_tap,
-                               "concurrent_streams": max(1, min(args.substreams, n)),
-                               "achieved_conv_io_only": (b["conv_io"] + b["weights"]) / (mean_ms * 1e-3) / 1e9}
-        else:
-            res["roofline"] = None
-        if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(sd, torch.from_numpy(image_all[:4]))
+        step_bytes = (cfg["algo_mb"] * n + cfg["weights_mb"]) * 1e6
+        fr = step_bytes / (ms_dstep * 1e-3) / 1e9
+        res["roofline_step"] = {"bound": "hbm", "achieved": fr, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fr / HBM_PEAK_GBS,
+                                "note": f"whole denoise step per GPU: SURVEY 8(d) {cfg['algo_mb']} MB/sample + {cfg['weights_mb']} MB weights, over ms_per_denoise_step",
+                                "algorithmic_tflops": cfg["gflop"] * n / ms_dstep, "mfma_util": (3.0 if f16 else 16.0) * cfg["gflop"] * n / ms_dstep / MFMA_PEAK_TFLOPS}
+        res["roofline"] = None
+        if taps:
+            m_dom, c_dom = mean_ms(dom)
+            if c_dom:
+                r = op_roofline(eng.op_info[dom], n_tap, m_dom, f16)
+                traffic, src = None, None
+                pmc = os.path.join(ROOT, "profiles", "r01_pmc_dominant_kernel.json")
+                if args.config in ("c2", "c3shard") and f16 and os.path.exists(pmc):
+                    # NOT measured in this run: HBM bytes per launch of this shape from committed rocprofv3 --pmc passes
+                    # (2 x FETCH_SIZE + WRITE_SIZE, KiB, separate passes, per MI355X_MICROARCH.md) at 64 samples per launch,
+                    # scaled by samples per launch (every byte is per-sample work)
+                    pj = json.load(open(pmc))
+                    traffic, src = pj.get("hbm_bytes") * n_tap / 64, "offline PMC constant (profiles/r01_pmc_dominant_kernel.json), not collected in this run"
+                o = eng.op_info[dom]
+                r.update({"traffic": traffic, "traffic_source": src, "launches_timed": c_dom, "concurrent_streams": nsub,
+                          "launches_per_denoise_step": len(groups[dom_key]),
+                          "kernel": f"ccdm::k_conv (engine op {dom}, {eng.op_names[dom]}: conv3x3 {o['cin']}->{o['cout']} @{o['hout']}x{o['wout']}, GN+SiLU on load)"})
+                res["roofline"] = r
+            m_h, c_h = mean_ms(heavy)
+            if c_h and heavy != dom:
+                o = eng.op_info[heavy]
+                r = op_roofline(o, n_tap, m_h, f16)
+                r.update({"launches_timed": c_h, "kernel": f"ccdm::k_conv (engine op {heavy}, {eng.op_names[heavy]}: conv3x3 {o['cin']}->{o['cout']} @{o['hout']}x{o['wout']}, "
+                                                           "GN+SiLU on load; the longest single launch of the step)"})
+                res["roofline_heaviest"] = r
+            if attn is not None:
+                m_a, c_a = mean_ms(attn)
+                if c_a:
+                    o = eng.op_info[attn]
+                    fl = o["flop"] * n_tap
+                    res["roofline_attention"] = {
+                        "bound": "mfma", "achieved": fl / (m_a * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": fl / (m_a * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "mfma_util": 3.0 * fl / (m_a * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
+                        "avg_launch_ms": m_a, "launches_timed": c_a, "traffic": None,
+                        "kernel": f"ccdm::k_attention_mfma (engine op {attn}, {eng.op_names[attn]}: T={o['T']}, C={o['C']}, {o['heads']} heads of {o['C'] // o['heads']})",
+                        "note": "frac = algorithmic FLOPs (4*T*T*C per sample) over the dense fp16 MFMA peak; mfma_util counts the 3 fp16 MFMAs each product is made of"}
+
+    # ---- untimed extras (rank 0, single GPU): per-stage split of one tapped pass, the --substreams 2 figure, the CPU baseline ----
+    if world == 1 and not args.no_secondary and taps and nsub == 1:
+        for i in range(len(eng.op_info)):
+            eng.profile_op(i, capacity=n_dsteps)
+        one_pass()
+        torch.cuda.synchronize()
+        per_op = []
+        for i, o in enumerate(eng.op_info):
+            cnt, m, lo, hi = eng.profile_read(i)
+            per_op.append(dict(op=i, name=o["name"], kind=o["kind"], mean_us=m * 1e3, min_us=lo * 1e3, max_us=hi * 1e3,
+                               shape=(f"{o['cin']}->{o['cout']} k{o['k']} @{o['hout']}x{o['wout']}" if o["kind"] == "conv" else f"T={o['T']} C={o['C']}"),
+                               hbm_frac=(o["io_bytes"] * n + o["gn_read_bytes"] * n + o["weight_bytes"]) / max(m, 1e-9) / 1e6 / HBM_PEAK_GBS))
+        eng.profile_op(-1)
+        by_stage = {}
+        for p in per_op:
+            o = eng.op_info[p["op"]]
+            key = f"{o['hout']}x{o['wout']}" if o["kind"] == "conv" else "attention"
+            by_stage[key] = by_stage.get(key, 0.0) + p["mean_us"]
+        res["per_stage_us"] = {k_: round(v, 1) for k_, v in by_stage.items()}
+        res["per_stage_note"] = "sum of per-op mean launch times (HIP events around every op, one extra untimed pass) grouped by output size"
+        if args.per_op:
+            with open(args.per_op, "w") as fh:
+                json.dump(per_op, fh, indent=1)
+        if args.config == "c2" and args.rng == "philox" and n >= 2:
+            model.substreams = 2
+            one_pass()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            one_pass()
+            torch.cuda.synchronize()
+            res["substreams2"] = {"value": n / (time.perf_counter() - t1), "unit": "samples/s",
+                                  "note": "same workload walked as 2 concurrent sub-batches (bit-identical samples); secondary figure, 1 pass"}
+            model.substreams = args.substreams
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1 and args.config in ("c2", "c3shard"):
+            res["cpu_baseline"] = cpu_baseline(sd, torch.from_numpy(image_all[:4]), cfg)
         print(json.dumps(res))
     if world > 1:
         dist.barrier()

@@ -5,6 +5,7 @@
 // (/root/reference/ddpm/models/diffusion_denoising.py:189-212) with no host sync inside.
 #include "ccdm_common.h"
 
+#include <map>
 #include <vector>
 
 namespace ccdm {
@@ -30,10 +31,9 @@ struct ccdm_engine {
     hipGraphExec_t exec = nullptr;
     bool graph_valid = false;
     int graph_with_epilogue = -1;
-    // timing taps
-    int prof_op = -1;
-    std::vector<hipEvent_t> ev;
-    int prof_n = 0;
+    // timing taps: HIP events around every launch of the tapped ops (op index -> events, launches recorded)
+    struct Tap { std::vector<hipEvent_t> ev; int n = 0; };
+    std::map<int, Tap> taps;
 };
 
 using namespace ccdm;
@@ -47,11 +47,15 @@ static void drop_graph(ccdm_engine* e) {
 static int launch_step(ccdm_engine* e, int with_epilogue, hipStream_t s, bool profile) {
     for (size_t i = 0; i < e->ops.size(); ++i) {
         const Op& op = e->ops[i];
-        const bool tap = profile && (int)i == e->prof_op && (size_t)(2 * e->prof_n + 1) < e->ev.size();
-        if (tap) (void)hipEventRecord(e->ev[2 * e->prof_n], s);
+        ccdm_engine::Tap* tp = nullptr;
+        if (profile) {
+            auto it = e->taps.find((int)i);
+            if (it != e->taps.end() && (size_t)(2 * it->second.n + 1) < it->second.ev.size()) tp = &it->second;
+        }
+        if (tp) (void)hipEventRecord(tp->ev[2 * tp->n], s);
         int rc = op.kind == 0 ? launch_conv(op.conv, s)
                               : launch_attention(op.qkv, op.out, op.N, op.T, op.T, op.C, op.heads, op.order, s);
-        if (tap) { (void)hipEventRecord(e->ev[2 * e->prof_n + 1], s); e->prof_n++; }
+        if (tp) { (void)hipEventRecord(tp->ev[2 * tp->n + 1], s); tp->n++; }
         if (rc) return rc;
     }
     if (with_epilogue && e->has_post) {
@@ -73,7 +77,8 @@ extern "C" ccdm_engine* ccdm_engine_create(int32_t* step_counter) {
 extern "C" void ccdm_engine_destroy(ccdm_engine* e) {
     if (!e) return;
     drop_graph(e);
-    for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
+    for (auto& kv : e->taps)
+        for (hipEvent_t ev : kv.second.ev) (void)hipEventDestroy(ev);
     delete e;
 }
 
@@ -128,8 +133,11 @@ extern "C" int ccdm_engine_run(ccdm_engine* e, int first_row, int n_steps, int w
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_step_set, dim3(1), dim3(1), 0, s, e->step, (int32_t)first_row);
     CCDM_CHECK_LAUNCH("step_set");
-    const bool profile = e->prof_op >= 0;
-    if (profile) { use_graph = 0; e->prof_n = 0; }
+    const bool profile = !e->taps.empty();
+    if (profile) {
+        use_graph = 0;
+        if (first_row == 0) for (auto& kv : e->taps) kv.second.n = 0;     // a new sampling run starts a new series
+    }
     if (use_graph) {
         if (!e->graph_valid || e->graph_with_epilogue != with_epilogue) {
             drop_graph(e);
@@ -159,26 +167,34 @@ extern "C" int ccdm_engine_run(ccdm_engine* e, int first_row, int n_steps, int w
 
 extern "C" int ccdm_engine_profile_op(ccdm_engine* e, int op_index, int capacity) {
     CCDM_REQUIRE(e, "engine_profile_op: null engine");
-    e->prof_op = op_index;
-    e->prof_n = 0;
-    if (op_index < 0) return 0;
+    if (op_index < 0) {                                   // drop every tap
+        for (auto& kv : e->taps)
+            for (hipEvent_t ev : kv.second.ev) (void)hipEventDestroy(ev);
+        e->taps.clear();
+        return 0;
+    }
     CCDM_REQUIRE(op_index < (int)e->ops.size(), "engine_profile_op: op %d out of range", op_index);
-    while ((int)e->ev.size() < 2 * capacity) {
+    ccdm_engine::Tap& t = e->taps[op_index];
+    t.n = 0;
+    while ((int)t.ev.size() < 2 * capacity) {
         hipEvent_t ev;
         if (hipEventCreate(&ev) != hipSuccess) return fail("engine_profile_op: hipEventCreate failed");
-        e->ev.push_back(ev);
+        t.ev.push_back(ev);
     }
     return 0;
 }
 
-extern "C" int ccdm_engine_profile_read(ccdm_engine* e, double* mean_ms, double* min_ms, double* max_ms) {
+extern "C" int ccdm_engine_profile_read(ccdm_engine* e, int op_index, double* mean_ms, double* min_ms, double* max_ms) {
     CCDM_REQUIRE(e, "engine_profile_read: null engine");
+    auto it = e->taps.find(op_index);
+    CCDM_REQUIRE(it != e->taps.end(), "engine_profile_read: op %d is not tapped", op_index);
+    ccdm_engine::Tap& t = it->second;
     double sum = 0, mn = 1e30, mx = 0;
     int n = 0;
-    for (int i = 0; i < e->prof_n; ++i) {
+    for (int i = 0; i < t.n; ++i) {
         float ms = 0.f;
-        if (hipEventSynchronize(e->ev[2 * i + 1]) != hipSuccess) continue;
-        if (hipEventElapsedTime(&ms, e->ev[2 * i], e->ev[2 * i + 1]) != hipSuccess) continue;
+        if (hipEventSynchronize(t.ev[2 * i + 1]) != hipSuccess) continue;
+        if (hipEventElapsedTime(&ms, t.ev[2 * i], t.ev[2 * i + 1]) != hipSuccess) continue;
         sum += ms; if (ms < mn) mn = ms; if (ms > mx) mx = ms; ++n;
     }
     if (mean_ms) *mean_ms = n ? sum / n : 0.0;

@@ -85,12 +85,16 @@ def sample_sharded(model, x: torch.Tensor, condition: torch.Tensor, feature_cond
 
 
 def all_gather_ragged(local: torch.Tensor, n: int, world: int) -> torch.Tensor:
-    """all_gather of per-rank shards whose first dims follow shard_range (pads to the largest shard)."""
+    """all_gather of per-rank shards whose first dims follow shard_range (pads to the largest shard).  RCCL moves device
+    tensors directly; under the gloo backend (CPU tests, or several ranks sharing one GPU) the shards travel through the host."""
     sizes = [shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world)]
     m = max(sizes)
+    dev = local.device
     pad = local
-    if local.shape[0] < m:
-        pad = torch.cat([local, local.new_zeros((m - local.shape[0],) + tuple(local.shape[1:]))], 0)
+    if dist.get_backend() == "gloo" and local.is_cuda:
+        pad = pad.cpu()
+    if pad.shape[0] < m:
+        pad = torch.cat([pad, pad.new_zeros((m - pad.shape[0],) + tuple(pad.shape[1:]))], 0)
     bufs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad.contiguous())
-    return torch.cat([b[:s] for b, s in zip(bufs, sizes)], 0)
+    return torch.cat([b[:s] for b, s in zip(bufs, sizes)], 0).to(dev)

@@ -156,6 +156,19 @@ class SamplerEngine:
             args.skip_w = skip_w.data_ptr()
         hip.check(self.lib.ccdm_engine_add_conv(self._handle, C.byref(args)), "engine_add_conv " + wkey)
         self.op_names.append(wkey)
+        # algorithmic work of this launch per SAMPLE (SURVEY 8d accounting: conv io + one GroupNorm statistics read + weights;
+        # a fused 1x1 skip counts as the separate conv it replaces: its input read and its output write + re-read as residual)
+        io = 4 * (cin * hin * win + cout * hout * wout)
+        flop = 2 * cin * cout * ksize * ksize * hout * wout
+        wbytes = 4 * cout * cin * ksize * ksize
+        if skip_src is not None:
+            sc = sum(t.C for t in skip_src)
+            io += 4 * (sc * hout * wout + cout * hout * wout)
+            flop += 2 * sc * cout * hout * wout
+            wbytes += 4 * cout * sc
+        self.op_info.append(dict(kind="conv", name=wkey, cin=cin, cout=cout, k=ksize, hin=hin, win=win, hout=hout, wout=wout,
+                                 stride=stride, up=bool(up), gn=gn is not None, skip=skip_src is not None,
+                                 io_bytes=io, gn_read_bytes=(4 * cin * hin * win if gn is not None else 0), weight_bytes=wbytes, flop=flop))
         return out
 
     def _res(self, p: str, l, src: Sequence[DevTensor]) -> DevTensor:
@@ -179,6 +192,9 @@ class SamplerEngine:
         hip.check(self.lib.ccdm_engine_add_attention(self._handle, qkv.ptr, a.ptr, self.N, x.h * x.w, l.ch, l.heads,
                                                      1 if l.new_order else 0), "engine_add_attention")
         self.op_names.append(p + ".attention")
+        T_ = x.h * x.w
+        self.op_info.append(dict(kind="attention", name=p + ".attention", T=T_, C=l.ch, heads=l.heads, io_bytes=4 * 4 * l.ch * T_,
+                                 gn_read_bytes=0, weight_bytes=0, flop=4 * T_ * T_ * l.ch))
         return self._conv([a], p + ".proj_out", l.ch, 1, resid=x)
 
     def _layers(self, layers, src: Sequence[DevTensor]) -> DevTensor:
@@ -212,6 +228,7 @@ class SamplerEngine:
         if not self._handle:
             raise hip.CcdmHipError("engine_create: " + hip.last_error())
         self.op_names: List[str] = []
+        self.op_info: List[dict] = []
 
         # --- time-conditioning parameters: every ResBlock's emb_layers.1 concatenated -----------------
         ted, mc = spec.time_embed_dim, spec.model_channels
@@ -401,11 +418,13 @@ class SamplerEngine:
                 "the network output is not finite" + (": a staged activation left the range of the fp16 split (|a| >= 4094, "
                 "include/ccdm_hip.h); re-run with prec=PREC_F32" if self.prec == hip.PREC_F16X3 else " (exact-fp32 kernels: check the weights and inputs)"))
 
-    # timing taps for bench.py
+    # timing taps for bench.py: HIP events on the engine's stream around every launch of the tapped ops
     def profile_op(self, op_index: int, capacity: int = 4096) -> None:
+        """Tap one more op (op_index < 0: remove every tap)."""
         hip.check(self.lib.ccdm_engine_profile_op(self._handle, op_index, capacity), "engine_profile_op")
 
-    def profile_read(self) -> Tuple[int, float, float, float]:
+    def profile_read(self, op_index: int) -> Tuple[int, float, float, float]:
+        """(launches timed, mean ms, min ms, max ms) of a tapped op over the series recorded since the last run from row 0."""
         m, lo, hi = C.c_double(), C.c_double(), C.c_double()
-        n = hip.check(self.lib.ccdm_engine_profile_read(self._handle, C.byref(m), C.byref(lo), C.byref(hi)), "profile_read")
+        n = hip.check(self.lib.ccdm_engine_profile_read(self._handle, op_index, C.byref(m), C.byref(lo), C.byref(hi)), "profile_read")
         return n, m.value, lo.value, hi.value

@@ -96,7 +96,7 @@ SIGNATURES = {
     "ccdm_engine_set_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ccdm_engine_run": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ccdm_engine_profile_op": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
-    "ccdm_engine_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "ccdm_engine_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "ccdm_engine_describe_op": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int]),
 }
 

@@ -223,10 +223,12 @@ int ccdm_engine_set_run(ccdm_engine* e, const float* noise, int64_t noise_step_s
                         float* out_probs, int64_t* out_onehot, float* posterior_out);
 /* run `n_steps` denoise steps starting at table row `first_row`; use_graph: 0 eager launches, 1 HIP graph of one step */
 int ccdm_engine_run(ccdm_engine* e, int first_row, int n_steps, int with_epilogue, int use_graph, void* stream);
-/* timing taps: record HIP events around every launch of op `op_index` during the next run (max `capacity`
- * launches); ccdm_engine_profile_read returns the number of samples and their mean/min/max in ms. */
+/* timing taps: record HIP events around every launch of op `op_index` during the following runs (at most `capacity` launches
+ * per series; a run that starts at table row 0 starts a new series; tapped runs launch eagerly).  Several ops may be tapped;
+ * op_index < 0 removes every tap.  ccdm_engine_profile_read returns the number of samples of one tapped op and their
+ * mean/min/max in ms. */
 int ccdm_engine_profile_op(ccdm_engine* e, int op_index, int capacity);
-int ccdm_engine_profile_read(ccdm_engine* e, double* mean_ms, double* min_ms, double* max_ms);
+int ccdm_engine_profile_read(ccdm_engine* e, int op_index, double* mean_ms, double* min_ms, double* max_ms);
 /* describe op i: writes a short text ("conv3x3 32->32 @128x128 gn silu ...") */
 int ccdm_engine_describe_op(const ccdm_engine* e, int i, char* buf, int buflen);
 

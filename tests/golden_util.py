@@ -32,3 +32,28 @@ def block_tensors(seed, shapes, x_shape):
     x = rng.standard_normal(x_shape).astype(np.float32)
     emb = rng.standard_normal((x_shape[0], EMB_DIM)).astype(np.float32)
     return w, x, emb
+
+
+def harness_case(vote: str):
+    """Fixed inputs of the LIDC-harness golden (G14): (batches, evaluations, K, predict).  batches = [(image [B,1,H,W],
+    labels [B,4,K,H,W] one-hot, weights)], some annotations all-background; predict(call_index, n) -> the stand-in model's
+    output for the n = B*S samples of that batch: fp32 probabilities ("confidence") or int64 one-hot ("majority")."""
+    import torch
+    K, H, W, evaluations = 2, 32, 32, [1, 4, 8]
+    rng = np.random.default_rng(1400)
+    batches = []
+    for B in (2, 2, 1):
+        image = torch.from_numpy(rng.uniform(-1, 1, (B, 1, H, W)).astype(np.float32))
+        lab = rng.integers(0, K, (B, 4, H, W)) * (rng.random((B, 4, 1, 1)) > 0.3)          # ~30 % of the annotations are empty
+        lab[:, :, : H // 2] = 0
+        labels = torch.nn.functional.one_hot(torch.from_numpy(lab), K).permute(0, 1, 4, 2, 3).float()
+        batches.append((image, labels, np.tile(np.array([0.25] * 4), (B, 1))))
+
+    def predict(call, n):
+        g = np.random.default_rng(9000 + call)
+        logits = torch.from_numpy((2.0 * g.standard_normal((n, K, H, W))).astype(np.float32))
+        logits[:, 0, : H // 2] += 3.0
+        if vote == "confidence":
+            return torch.softmax(logits, dim=1)
+        return torch.nn.functional.one_hot(logits.argmax(1), K).permute(0, 3, 1, 2)          # int64, like max_prob_sample
+    return batches, evaluations, K, predict

@@ -338,7 +338,7 @@ def lidc_model(request):
     return model.to("cuda:0").eval(), sd
 
 
-def test_unet_step_vs_reference_golden(U, golden, lidc_model):
+def test_unet_step_vs_reference_golden(U, golden, lidc_model, parity_log):
     model, sd = lidc_model
     g = golden["g4_unet_step_lidc"]
     rng = np.random.default_rng(1234)
@@ -347,6 +347,7 @@ def test_unet_step_vs_reference_golden(U, golden, lidc_model):
     out = model(O.one_hot_bchw(idx, 2).to(U.DEV), image.to(U.DEV), t=torch.full((2,), 37.0), validation=True)["diffusion_out"]
     err = np.abs(out.cpu().numpy() - g["out"])
     print("unet step max|dp| =", err.max())
+    parity_log(f"g4_unet_step_lidc[prec={model.prec}]", max_dp=err.max(), bar=1e-4)
     assert err.max() < 1e-4                        # north_star tolerance on the output probabilities
     # per-sample timesteps
     tt = torch.tensor([37.0, 200.0])
@@ -355,7 +356,7 @@ def test_unet_step_vs_reference_golden(U, golden, lidc_model):
     assert (out2 - ref2).abs().max() < 1e-4
 
 
-def test_trajectory_teacher_forced_and_free_running(U, golden, lidc_model):
+def test_trajectory_teacher_forced_and_free_running(U, golden, lidc_model, parity_log):
     """G7: 10 strided steps, seed 42.  Teacher-forced (the reference's x_t fed to every step) the network
     output stays within 1e-4 and, given the same noise, the sampled indices match except at near-ties;
     free-running the final probabilities agree on almost every pixel."""
@@ -374,6 +375,7 @@ def test_trajectory_teacher_forced_and_free_running(U, golden, lidc_model):
         d = np.abs(out.cpu()[:, 0, ::16, ::16].numpy() - g[f"x0pred0_{j}"]).max()
         worst = max(worst, d)
     print("teacher-forced max|d x0pred| =", worst)
+    parity_log(f"g7_trajectory[prec={model.prec}]", teacher_forced_max_dx0=worst, bar=1e-4)
     assert worst < 1e-4
     if not host_rng_ok:
         pytest.skip("host exponential_ stream differs from the fixture host; seeded trajectory not comparable")
@@ -390,11 +392,13 @@ def test_trajectory_teacher_forced_and_free_running(U, golden, lidc_model):
             err = np.abs(out[:, 0].numpy() - g["out_confidence_c0"])
             frac = (err > 1e-3).mean()
             print(f"free-running: median|dp|={np.median(err):.2e} frac>1e-3={frac:.2e}")
+            parity_log(f"g7_trajectory[prec={model.prec}]", free_running_median_dp=np.median(err), free_running_frac_gt_1e3=frac)
             assert np.median(err) < 1e-5 and frac < 0.02
         else:
             assert out.dtype == torch.int64
             mism = (out.argmax(1).numpy() != unpack(g["out_majority"], (2, 128, 128))).mean()
             print(f"free-running majority mismatch rate = {mism:.2e}")
+            parity_log(f"g7_trajectory[prec={model.prec}]", free_running_majority_mismatch=mism)
             assert mism < 0.02
     model.step_T_sample = "confidence"
 
@@ -419,7 +423,7 @@ def test_caller_contract_g9(U, golden, lidc_model):
 
 
 @pytest.mark.parametrize("prec", PRECS, ids=PREC_IDS)
-def test_dino_concat_step_g8(U, golden, prec):
+def test_dino_concat_step_g8(U, golden, prec, parity_log):
     g = golden["g8_unet_step_dino"]
     fce = dict(type="dino", channels=384, output_stride=8, scale="single", target_layer=10)
     model = build_model(250, "cosine", None, [(3, 64, 128), (20, 64, 128)], (3, 64, 128), "unet_openai",
@@ -435,6 +439,7 @@ def test_dino_concat_step_g8(U, golden, prec):
     out = model(O.one_hot_bchw(idx, 20).to(U.DEV), img.to(U.DEV), feat.to(U.DEV), t=torch.full((1,), 120.0), validation=True)["diffusion_out"]
     err = np.abs(out.cpu().numpy() - g["out"])
     print("dino step max|dp| =", err.max())
+    parity_log(f"g8_unet_step_dino[prec={prec}]", max_dp=err.max(), bar=1e-4)
     assert err.max() < 1e-4
     with pytest.raises(ValueError, match="feature"):
         model(O.one_hot_bchw(idx, 20).to(U.DEV), img.to(U.DEV), None, t=torch.full((1,), 120.0), validation=True)
@@ -548,7 +553,7 @@ def test_f16x3_dynamic_range(U, scale):
     assert rel < 3e-6
 
 
-def test_c4_shaped_step_vs_oracle(U):
+def test_c4_shaped_step_vs_oracle(U, parity_log):
     """BASELINE config C4 shape (Cityscapes 256x512, K=20, DINO features at stride 8, base 32), N=1, one U-Net step
     against the oracle: 6-level network, 2048/512/128-token attention, 448-channel widened block."""
     fce = dict(type="dino", channels=384, output_stride=8, scale="single", target_layer=10)
@@ -570,6 +575,7 @@ def test_c4_shaped_step_vs_oracle(U):
     ref = O.unet_forward(sd, dict(LIDC_CFG, feature_condition_idx=[10]), x, img, feat, t)["diffusion_out"]
     err = (out - ref).abs().max().item()
     print("C4-shaped step max|dp| =", err)
+    parity_log("c4_step_n1_vs_oracle", max_dp=err, bar=1e-4)
     assert err < 1e-4
     # two strided sampling steps run end to end with the device RNG and stay normalised
     model.rng, model.philox_seed = "philox", 1
@@ -577,51 +583,181 @@ def test_c4_shaped_step_vs_oracle(U):
     assert torch.isfinite(y).all() and (y.sum(1) - 1).abs().max() < 1e-5
 
 
-def test_c5_shaped_step_properties(U):
-    """BASELINE config C5 shape (Cityscapes 512x1024, K=20, base 64, 7 levels, attention over 8192 tokens), N=1:
-    runs, is normalised, and is bit-reproducible.  (The oracle needs minutes per step at this size.)"""
+def _c5_model():
     bp = dict(LIDC_BP, base_channels=64)
     model = build_model(250, "cosine", None, [(3, 512, 1024), (20, 512, 1024)], (3, 512, 1024), "unet_openai", bp,
                         "datasets.cityscapes", "confidence", None)
     assert model.unet.spec.num_params() == 29306996                     # SURVEY §8a A9
-    model.unet.load_state_dict({k: torch.from_numpy(v) for k, v in make_synthetic_state_dict(model.unet.spec, 5).items()}, strict=True)
-    model = model.to("cuda:0").eval()
-    model.prec = hip.PREC_F16X3
+    sd = {k: torch.from_numpy(v) for k, v in make_synthetic_state_dict(model.unet.spec, 5).items()}
+    model.unet.load_state_dict(sd, strict=True)
+    return model.to("cuda:0").eval(), sd
+
+
+def test_c5_step_vs_reference_golden_g12(U, golden, parity_log):
+    """BASELINE config C5 (Cityscapes 512x1024, K=20, base 64, 7 levels, attention over 8192/2048/512/128 tokens): one U-Net step
+    against G12 — the REFERENCE's own output for these seeded weights and inputs (tools/gen_goldens_c5.py) on a lattice of every
+    8th pixel, all classes.  Then the per-GPU shard of C5 (N=4): the same sample inside a batch of four reproduces its N=1
+    output bit-for-bit, every sample is normalised, and the run is reproducible."""
+    g = golden["g12_unet_step_c5"]
+    model, sd = _c5_model()
+    assert int(g["params"]) == model.unet.spec.num_params()
     rng = np.random.default_rng(5)
-    img = torch.from_numpy(rng.standard_normal((1, 3, 512, 1024)).astype(np.float32)).to(U.DEV)
-    x = O.one_hot_bchw(torch.from_numpy(rng.integers(0, 20, (1, 512, 1024))), 20).to(U.DEV)
-    t = torch.full((1,), 120.0)
-    a = model(x, img, t=t, validation=True)["diffusion_out"]
-    b = model(x, img, t=t, validation=True)["diffusion_out"]
-    assert torch.isfinite(a).all() and (a.sum(1) - 1).abs().max() < 1e-5 and a.std() > 1e-3
-    assert torch.equal(a, b)
+    img = torch.from_numpy(rng.standard_normal((1, 3, 512, 1024)).astype(np.float32))
+    idx = torch.from_numpy(rng.integers(0, 20, (1, 512, 1024)))
+    x = O.one_hot_bchw(idx, 20)
+    t = torch.full((1,), float(g["t"]))
+    a = model(x.to(U.DEV), img.to(U.DEV), t=t, validation=True)["diffusion_out"]
+    got = a.cpu()
+    err = np.abs(got[:, :, ::8, ::8].numpy() - g["lattice"]).max()
+    dmean = np.abs(got.double().mean(dim=(0, 2, 3)).numpy() - g["class_mean"]).max()
+    mism = (got.argmax(1)[:, ::4, ::4].numpy() != g["argmax_s4"]).mean()
+    print(f"C5 step vs reference: max|dp|={err:.3e} max|d class mean|={dmean:.3e} argmax mismatch={mism:.2e}")
+    parity_log("g12_unet_step_c5", max_dp=err, max_d_class_mean=dmean, argmax_mismatch_rate=mism, bar=1e-4)
+    assert err < 1e-4 and dmean < 1e-6
+    assert mism < 1e-3                              # only exact near-ties between two classes may flip
+    assert (a.sum(1) - 1).abs().max() < 1e-5
+    # ---- the per-GPU shard (N=4): sample 2 is the golden's sample, the others are fresh draws ----
+    img4 = torch.from_numpy(rng.standard_normal((4, 3, 512, 1024)).astype(np.float32))
+    x4 = O.one_hot_bchw(torch.from_numpy(rng.integers(0, 20, (4, 512, 1024))), 20)
+    img4[2], x4[2] = img[0], x[0]
+    t4 = torch.full((4,), float(g["t"]))
+    b = model(x4.to(U.DEV), img4.to(U.DEV), t=t4, validation=True)["diffusion_out"]
+    b2 = model(x4.to(U.DEV), img4.to(U.DEV), t=t4, validation=True)["diffusion_out"]
+    assert torch.equal(b, b2), "run-to-run nondeterminism at the C5 shard size"
+    assert torch.equal(b[2], a[0]), "a sample's output depends on its batch"
+    assert torch.isfinite(b).all() and (b.sum(1) - 1).abs().max() < 1e-5 and b.std() > 1e-3
+    # two strided sampling steps of the shard with the device RNG
+    model.rng, model.philox_seed = "philox", 3
+    y = model(x4.to(U.DEV), img4.to(U.DEV), t=torch.as_tensor(10002))["diffusion_out"]
+    assert y.shape == (4, 20, 512, 1024) and torch.isfinite(y).all() and (y.sum(1) - 1).abs().max() < 1e-5
 
 
-def test_c3_shaped_t1000_sharded_sampling(U):
-    """BASELINE config C3 shape: T=1000, S samples per image, batch sharded by `sample_sharded` (single process here:
-    the multi-rank path is the gloo test).  Strided 5-step walk from t=1000; the shard slices reproduce the full batch."""
+def test_c3_t1000_steps_vs_reference_golden_g13(U, golden, parity_log):
+    """T = 1000 (BASELINE config C3): U-Net output and normalised posterior at t in {1000, 500, 2} against the reference's own
+    outputs (G13), N=2."""
+    g = golden["g13_c3_steps"]
+    model = build_model(1000, "cosine", {"s": 0.008}, [(1, 128, 128), (2, 128, 128)], (1, 128, 128), "unet_openai", LIDC_BP,
+                        "datasets.lidc", "confidence", None)
+    model.unet.load_state_dict({k: torch.from_numpy(v) for k, v in make_synthetic_state_dict(model.unet.spec, 0).items()}, strict=True)
+    model = model.to("cuda:0").eval()
+    assert np.array_equal(model.diffusion.cumalphas[-4:].cpu().numpy(), g["cumalphas_tail"])
+    rng = np.random.default_rng(13)
+    img = torch.from_numpy(rng.uniform(-1, 1, (2, 1, 128, 128)).astype(np.float32)).to(U.DEV)
+    worst_x0 = worst_p = 0.0
+    for t in (1000, 500, 2):
+        idx = torch.from_numpy(rng.integers(0, 2, (2, 128, 128)))
+        assert np.array_equal(np.packbits(idx.numpy().astype(np.uint8).reshape(-1)), g[f"xt_{t}"])
+        x = O.one_hot_bchw(idx, 2).to(U.DEV)
+        tt = torch.full((2,), t)
+        x0 = model(x, img, t=tt.float(), validation=True)["diffusion_out"]
+        p = torch.clamp(model.diffusion.theta_post_prob(x, x0.contiguous(), tt.to(U.DEV)), min=1e-12)
+        p = p / p.sum(1, keepdim=True)
+        worst_x0 = max(worst_x0, np.abs(x0.cpu()[:, 0, ::4, ::4].numpy() - g[f"x0_{t}"]).max())
+        worst_p = max(worst_p, np.abs(p.cpu()[:, 0, ::4, ::4].numpy() - g[f"post_{t}"]).max())
+    print(f"T=1000 steps vs reference: max|d x0|={worst_x0:.3e} max|d posterior|={worst_p:.3e}")
+    parity_log("g13_c3_steps", max_dx0=worst_x0, max_dposterior=worst_p, bar=1e-4)
+    assert worst_x0 < 1e-4 and worst_p < 1e-4
+
+
+def test_c3_full_size_t1000(U, parity_log):
+    """BASELINE config C3 at its per-GPU size: N = 64 = 4 images x S = 16 draws (repeat_interleave, sample index fastest), T = 1000.
+    (a) three teacher-forced steps at t in {1000, 500, 2} against the oracle on the whole N=64 batch: U-Net output <= 1e-4, and
+        given the oracle's probabilities' noise the sampled class indices agree except at near-ties;
+    (b) one full 1000-step walk: one-hot, reproducible bit-for-bit, a shard of it reproduces its slice, and the [B_img, S]
+        reshape of the caller (evaluate_lidc_uncertainty.py:103) groups the S draws of one image."""
     from ccdm_stochastic_segmentation_amd.distributed import sample_sharded, shard_range
     model = build_model(1000, "cosine", {"s": 0.008}, [(1, 128, 128), (2, 128, 128)], (1, 128, 128), "unet_openai", LIDC_BP,
                         "datasets.lidc", "majority", None)
-    model.unet.load_state_dict({k: torch.from_numpy(v) for k, v in make_synthetic_state_dict(model.unet.spec, 0).items()}, strict=True)
+    sd = {k: torch.from_numpy(v) for k, v in make_synthetic_state_dict(model.unet.spec, 0).items()}
+    model.unet.load_state_dict(sd, strict=True)
     model = model.to("cuda:0").eval()
     assert model.time_steps == 1000
-    model.prec, model.rng, model.philox_seed = hip.PREC_F16X3, "philox", 7
-    rng = np.random.default_rng(9)
-    B_img, S = 2, 4
-    image = torch.from_numpy(rng.uniform(-1, 1, (B_img, 1, 128, 128)).astype(np.float32)).to(U.DEV).repeat_interleave(S, dim=0)
-    x = O.one_hot_bchw(torch.from_numpy(rng.integers(0, 2, (B_img * S, 128, 128))), 2).to(U.DEV)
-    t = torch.as_tensor(10005)
-    full = sample_sharded(model, x, image, t=t)
-    assert full.dtype == torch.int64 and full.shape == (B_img * S, 2, 128, 128) and (full.sum(1) == 1).all()
-    # what rank 1 of 3 would compute for its shard (Philox keyed by global sample index)
-    lo, hi = shard_range(B_img * S, 1, 3)
-    model.sample_offset, model.noise_slice = lo, (B_img * S, lo)
-    part = model(x[lo:hi], image[lo:hi], t=t)["diffusion_out"]
+    sched = O.make_schedule("cosine", 1000, {"s": 0.008})
+    rng = np.random.default_rng(33)
+    B_img, S = 4, 16
+    N = B_img * S
+    img_b = torch.from_numpy(rng.uniform(-1, 1, (B_img, 1, 128, 128)).astype(np.float32))
+    image = img_b.repeat_interleave(S, dim=0)
+    torch.set_num_threads(16)
+    worst = 0.0
+    for t in (1000, 500, 2):
+        idx = torch.from_numpy(rng.integers(0, 2, (N, 128, 128)))
+        x = O.one_hot_bchw(idx, 2)
+        tt = torch.full((N,), float(t))
+        got = model(x.to(U.DEV), image.to(U.DEV), t=tt, validation=True)["diffusion_out"].cpu()
+        ref = O.unet_forward(sd, LIDC_CFG, x, image, None, tt)["diffusion_out"]
+        d = (got - ref).abs().max().item()
+        worst = max(worst, d)
+        # posterior + draw of this step, teacher-forced: the engine's step with host noise vs the oracle's
+        a, c = O.posterior_coeffs(sched[1], sched[2], t)
+        p_ref = O.normalise_probs(torch.clamp(O.theta_post_prob_ref(x, ref, a, c), min=1e-12))        # [N,H,W,K]
+        e = O.draw_exponential((N * 128 * 128, 2), torch.Generator().manual_seed(t)).reshape(N, 128, 128, 2)
+        idx_ref = O.sample_index(p_ref, e)
+        r = U.posterior_sample(U.nhwc(got).reshape(N, 128 * 128, 2), idx.to(torch.uint8).reshape(N, -1).to(U.DEV), a, c,
+                               hip.STEP_SAMPLE, softmax=False, noise=e.reshape(N, -1).contiguous().to(U.DEV))
+        mism = (r["xt_next"].reshape(N, 128, 128).long() != idx_ref).float().mean().item()
+        print(f"C3 N=64 t={t}: max|d x0|={d:.3e}, sampled-index mismatch (near-ties)={mism:.2e}")
+        parity_log("c3_n64_t1000_teacher_forced", **{f"max_dx0_t{t}": d, f"index_mismatch_t{t}": mism})
+        assert d < 1e-4 and mism < 1e-3
+    parity_log("c3_n64_t1000_teacher_forced", max_dx0=worst, bar=1e-4)
+    # ---- full T=1000 walk ----
+    model.rng, model.philox_seed = "philox", 7
+    x = O.one_hot_bchw(torch.from_numpy(rng.integers(0, 2, (N, 128, 128))), 2).to(U.DEV)
+    image = image.to(U.DEV)
+    full = sample_sharded(model, x, image)                              # t=None: all 1000 steps
+    again = sample_sharded(model, x, image)
+    assert full.dtype == torch.int64 and full.shape == (N, 2, 128, 128) and (full.sum(1) == 1).all()
+    assert torch.equal(full, again), "run-to-run nondeterminism over 1000 steps"
+    lo, hi = shard_range(N, 3, 8)                                       # what rank 3 of 8 computes: 8 samples
+    model.sample_offset, model.noise_slice = lo, (N, lo)
+    part = model(x[lo:hi], image[lo:hi])["diffusion_out"]
     model.sample_offset, model.noise_slice = 0, None
-    assert torch.equal(part, full[lo:hi])
-    pred = full.reshape(B_img, S, 2, 128, 128)          # [B_img, S, K, H, W] as evaluate_lidc_uncertainty.py:103
-    assert pred.shape[1] == S
+    assert torch.equal(part, full[lo:hi]), "a shard does not reproduce its slice of the full batch"
+    pred = full.reshape(B_img, S, 2, 128, 128)                          # [B_img, S, K, H, W] as evaluate_lidc_uncertainty.py:103
+    fg = pred[:, :, 1].float().mean(dim=(2, 3))                         # foreground fraction per draw
+    assert pred.shape[1] == S and torch.isfinite(fg).all()
+    # the draws of one image differ from each other (stochastic segmentation), yet every draw is a valid map
+    assert (pred[:, 0] != pred[:, 1]).any()
+
+
+def test_c4_n16_two_strided_steps_vs_oracle(U, parity_log):
+    """BASELINE config C4 at its batch size (N = 16, 256x512, K = 20, DINO-feature concat, base 32): the first U-Net step of all 16
+    samples runs in one batch; samples 0 and 15 are compared with the oracle (teacher-forced <= 1e-4), then the two-step strided
+    walk t = 250 -> 1 with the host noise both sides share (free-running: equal except downstream of near-tie flips)."""
+    fce = dict(type="dino", channels=384, output_stride=8, scale="single", target_layer=10)
+    model = build_model(250, "cosine", None, [(3, 256, 512), (20, 256, 512)], (3, 256, 512), "unet_openai", LIDC_BP,
+                        "datasets.cityscapes", "confidence", fce)
+    sd = {k: torch.from_numpy(v) for k, v in make_synthetic_state_dict(model.unet.spec, 4).items()}
+    model.unet.load_state_dict(sd, strict=True)
+    model = model.to("cuda:0").eval()
+    rng = np.random.default_rng(44)
+    N, K, H, W = 16, 20, 256, 512
+    img = torch.from_numpy(rng.standard_normal((N, 3, H, W)).astype(np.float32))
+    feat = torch.from_numpy(rng.standard_normal((N, 384, H // 8, W // 8)).astype(np.float32))
+    x = O.one_hot_bchw(torch.from_numpy(rng.integers(0, K, (N, H, W))), K)
+    pick = [0, 15]
+    cfg = dict(LIDC_CFG, feature_condition_idx=[10])
+    torch.set_num_threads(16)
+    got = model(x.to(U.DEV), img.to(U.DEV), feat.to(U.DEV), t=torch.full((N,), 250.0), validation=True)["diffusion_out"].cpu()
+    ref = O.unet_forward(sd, cfg, x[pick], img[pick], feat[pick], torch.full((2,), 250.0))["diffusion_out"]
+    err = (got[pick] - ref).abs().max().item()
+    print("C4 N=16 first step, samples 0 and 15: max|dp| =", err)
+    assert err < 1e-4
+    # two strided steps with the reference's host-noise order: one [N*H*W, K] draw for the step with t > 1
+    model.rng = "torch_cpu"
+    torch.manual_seed(444)
+    out = model(x.to(U.DEV), img.to(U.DEV), feat.to(U.DEV), t=torch.as_tensor(10002))["diffusion_out"].cpu()
+    torch.manual_seed(444)
+    e = torch.empty(N * H * W, K).exponential_(1).reshape(N, H * W * K)
+    sched = O.make_schedule("cosine", 250, None)
+    oref = O.forward_denoising(sd, cfg, sched, x[pick], img[pick], feat[pick], 10002, "confidence",
+                               noise=[e[pick].reshape(2 * H * W, K), None])["diffusion_out"]
+    d = (out[pick] - oref).abs()
+    frac = (d > 1e-3).float().mean().item()
+    print(f"C4 N=16 two strided steps, samples 0 and 15: median|dp|={d.median().item():.2e} frac>1e-3={frac:.2e}")
+    parity_log("c4_n16_two_steps_vs_oracle", first_step_max_dp=err, free_running_median_dp=d.median().item(), free_running_frac_gt_1e3=frac, bar=1e-4)
+    assert (out.sum(1) - 1).abs().max() < 1e-5 and torch.isfinite(out).all()
+    assert d.median().item() < 1e-5 and frac < 0.02
 
 
 @pytest.mark.gpu
@@ -843,3 +979,233 @@ def test_attention_head_width_64_padded_rows(U, C, T, Ta):
     got = out.cpu()
     np.testing.assert_allclose(got[:, :T].permute(0, 2, 1).numpy(), ref.numpy(), rtol=0, atol=1e-5)
     assert torch.all(got[:, T:] == -5.0)
+
+
+# ------------------------------------------------------------------------------------------ F16X3 range: loud, never clipped
+@pytest.mark.parametrize("scale", [1e-4, 1e4])
+def test_f16x3_out_of_range_inputs(U, scale):
+    """Raw (un-normalised) conv inputs at the two ends of the fp16 split's window.  |x| ~ 1e-4: the split degrades gracefully —
+    the ABSOLUTE error stays below 2^-29 * sum|w| per output (include/ccdm_hip.h).  |x| ~ 1e4 (> 4094): the output is NaN/Inf,
+    never a silently clipped number."""
+    rng = np.random.default_rng(77)
+    x = rnd(rng, 2, 32, 16, 16, scale=scale)
+    w = rnd(rng, 64, 32, 3, 3, scale=1.0 / np.sqrt(288))
+    out, _ = U.conv2d([U.nhwc(x)], w.numpy(), np.zeros(64, dtype=np.float32), 3, prec=hip.PREC_F16X3)
+    got = U.bchw(out)
+    if scale > 1:
+        assert not torch.isfinite(got).all(), "an input beyond the fp16 range must not produce finite (clipped) numbers"
+        x[0, 0, 0, 0] = 0.0
+        assert (x.abs() > 4094).any()
+    else:
+        ref = F.conv2d(x.double(), w.double(), None, padding=1).float()
+        bound = 2.0 ** -29 * w.abs().sum(dim=(1, 2, 3)).reshape(1, -1, 1, 1) + 1e-7 * ref.abs()
+        assert torch.isfinite(got).all() and ((got - ref).abs() <= bound).all()
+
+
+def _trained_like_state_dict(spec, seed):
+    """Synthetic weights with the pathologies of a trained checkpoint that random init never shows: a few output channels of the
+    stem and of the first ResBlock scaled x300 (outlier channels on the raw residual stream, which Downsample / skip 1x1 / Upsample
+    convs read WITHOUT a GroupNorm in front), and large GroupNorm gains."""
+    sd = {k: torch.from_numpy(v).clone() for k, v in make_synthetic_state_dict(spec, seed).items()}
+    sd["input_blocks.0.0.weight"][3] *= 300.0
+    sd["input_blocks.0.0.bias"][3] += 40.0
+    sd["input_blocks.1.0.out_layers.3.weight"][5] *= 300.0
+    sd["input_blocks.2.0.out_layers.3.weight"][7] *= 3000.0            # residual stream channel 7 ends up beyond +-4094
+    sd["input_blocks.2.0.out_layers.0.weight"] *= 8.0                  # large gamma
+    return sd
+
+
+def test_trained_like_weights_overflow_is_loud_and_falls_back(U, parity_log):
+    """Outlier channels push a raw conv input of the F16X3 path beyond fp16: with on_range_error='raise' the call fails with
+    CcdmRangeError; by default it is repeated with the exact-fp32 kernels and equals an all-fp32 run bit-for-bit (and the oracle
+    within 1e-4) — never clipped numbers."""
+    model = build_model(250, "cosine", {"s": 0.008}, [(1, 128, 128), (2, 128, 128)], (1, 128, 128), "unet_openai", LIDC_BP,
+                        "datasets.lidc", "confidence", None)
+    sd = _trained_like_state_dict(model.unet.spec, 0)
+    model.unet.load_state_dict(sd, strict=True)
+    model = model.to("cuda:0").eval()
+    rng = np.random.default_rng(8)
+    img = torch.from_numpy(rng.uniform(-1, 1, (2, 1, 128, 128)).astype(np.float32))
+    x = O.one_hot_bchw(torch.from_numpy(rng.integers(0, 2, (2, 128, 128))), 2)
+    t = torch.full((2,), 60.0)
+    ref = O.unet_forward(sd, LIDC_CFG, x, img, None, t)["diffusion_out"]
+    assert torch.isfinite(ref).all()
+    model.prec, model.on_range_error = hip.PREC_F16X3, "raise"
+    with pytest.raises(hip.CcdmRangeError, match="range of the fp16 split"):
+        model(x.to(U.DEV), img.to(U.DEV), t=t, validation=True)
+    model.on_range_error = "f32"
+    got = model(x.to(U.DEV), img.to(U.DEV), t=t, validation=True)["diffusion_out"].cpu()
+    model.prec = hip.PREC_F32
+    exact = model(x.to(U.DEV), img.to(U.DEV), t=t, validation=True)["diffusion_out"].cpu()
+    assert torch.equal(got, exact)
+    err = (got - ref).abs().max().item()
+    parity_log("trained_like_outlier_weights_f32_fallback", max_dp=err, bar=1e-4)
+    assert err < 1e-4
+    # the sampling loop takes the same route (and reproduces the all-fp32 samples: same Philox counters)
+    model.prec, model.rng, model.philox_seed = hip.PREC_F16X3, "philox", 5
+    a = model(x.to(U.DEV), img.to(U.DEV), t=torch.as_tensor(10003))["diffusion_out"]
+    model.prec = hip.PREC_F32
+    b = model(x.to(U.DEV), img.to(U.DEV), t=torch.as_tensor(10003))["diffusion_out"]
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+def test_trained_like_weights_in_range_stay_on_the_fast_path(U, parity_log):
+    """Outlier channels x300 that stay inside the split's window: the F16X3 path itself holds the 1e-4 bar (no fallback)."""
+    model = build_model(250, "cosine", {"s": 0.008}, [(1, 128, 128), (2, 128, 128)], (1, 128, 128), "unet_openai", LIDC_BP,
+                        "datasets.lidc", "confidence", None)
+    sd = {k: torch.from_numpy(v).clone() for k, v in make_synthetic_state_dict(model.unet.spec, 0).items()}
+    sd["input_blocks.0.0.weight"][3] *= 300.0
+    sd["input_blocks.1.0.out_layers.3.weight"][5] *= 300.0
+    sd["input_blocks.2.0.out_layers.0.weight"] *= 8.0
+    model.unet.load_state_dict(sd, strict=True)
+    model = model.to("cuda:0").eval()
+    model.on_range_error = "raise"
+    rng = np.random.default_rng(9)
+    img = torch.from_numpy(rng.uniform(-1, 1, (2, 1, 128, 128)).astype(np.float32))
+    x = O.one_hot_bchw(torch.from_numpy(rng.integers(0, 2, (2, 128, 128))), 2)
+    t = torch.full((2,), 60.0)
+    got = model(x.to(U.DEV), img.to(U.DEV), t=t, validation=True)["diffusion_out"].cpu()
+    ref = O.unet_forward(sd, LIDC_CFG, x, img, None, t)["diffusion_out"]
+    err = (got - ref).abs().max().item()
+    parity_log("trained_like_outlier_weights_in_range", max_dp=err, bar=1e-4)
+    assert err < 1e-4
+
+
+# ------------------------------------------------------------------------------------------ A14 variants
+def test_softmax_output_off_and_ce_head(U, parity_log):
+    """`softmax_output: no` (unet.py:706-713: the head conv's logits go to the posterior un-normalised) and `ce_head: yes`
+    (unet.py:716-726,805-807: a parallel GN-SiLU-conv head with K-1 logits) against the oracle."""
+    bp = dict(LIDC_BP, softmax_output=False, ce_head=True, channel_mult=(1, 2), attention_resolutions=[2])
+    K, H, W, N = 4, 32, 32, 2
+    model = build_model(50, "cosine", {"s": 0.008}, [(1, H, W), (K, H, W)], (1, H, W), "unet_openai", bp, "datasets.lidc", "confidence", None)
+    sd = {k: torch.from_numpy(v) for k, v in make_synthetic_state_dict(model.unet.spec, 21).items()}
+    assert "out_ce.2.weight" in sd and sd["out_ce.2.weight"].shape[0] == K - 1
+    model.unet.load_state_dict(sd, strict=True)
+    model = model.to("cuda:0").eval()
+    rng = np.random.default_rng(21)
+    img = torch.from_numpy(rng.uniform(-1, 1, (N, 1, H, W)).astype(np.float32))
+    x = O.one_hot_bchw(torch.from_numpy(rng.integers(0, K, (N, H, W))), K)
+    t = torch.tensor([7.0, 33.0])
+    r = model(x.to(U.DEV), img.to(U.DEV), t=t, validation=True)
+    ref = O.unet_forward(sd, dict(LIDC_CFG, softmax_output=False, ce_head=True), x, img, None, t)
+    e1 = (r["diffusion_out"].cpu() - ref["diffusion_out"]).abs().max().item()
+    e2 = (r["logits"].cpu() - ref["logits"]).abs().max().item()
+    parity_log("a14_softmax_off_ce_head", max_d_logits=e1, max_d_ce_logits=e2)
+    assert r["logits"].shape == (N, K - 1, H, W)
+    assert e1 < 2e-4 and e2 < 2e-4           # raw logits (O(1) values), not probabilities
+    # the sampler consumes the un-normalised head output exactly like the reference: posterior(x_t, logits)
+    model.rng = "torch_cpu"
+    torch.manual_seed(3)
+    out = model(x.to(U.DEV), img.to(U.DEV), t=torch.as_tensor(2))["diffusion_out"].cpu()
+    torch.manual_seed(3)
+    oref = O.forward_denoising(sd, dict(LIDC_CFG, softmax_output=False, ce_head=True), O.make_schedule("cosine", 50, {"s": 0.008}), x, img, None, 2,
+                               "confidence")["diffusion_out"]
+    d = (out - oref).abs()
+    assert d.median().item() < 1e-5 and (d > 1e-3).float().mean().item() < 0.02
+
+
+# ------------------------------------------------------------------------------------------ two ranks of the REAL model
+RANKS_WORKER = r"""
+import os, sys, json, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["CCDM_ROOT"])
+from ccdm_stochastic_segmentation_amd import build_model, make_synthetic_state_dict, hip
+from ccdm_stochastic_segmentation_amd.distributed import init_from_env, sample_sharded
+rank, local, world = init_from_env("gloo")            # both ranks share cuda:0; the gather goes through the host
+torch.cuda.set_device(0)
+bp = dict(base_channels=32, channel_mult=None, attention_resolutions=[32, 16, 8], num_heads=1, num_head_channels=32, softmax_output=True)
+N = 7
+g = np.random.default_rng(5)
+img = torch.from_numpy(g.uniform(-1, 1, (N, 1, 128, 128)).astype(np.float32)).cuda()
+x = torch.nn.functional.one_hot(torch.from_numpy(g.integers(0, 2, (N, 128, 128))), 2).permute(0, 3, 1, 2).float().cuda()
+res = {}
+for vote, rng_mode, gather in (("confidence", "philox", True), ("majority", "philox", "index"), ("confidence", "torch_cpu", True)):
+    model = build_model(250, "cosine", {"s": 0.008}, [(1, 128, 128), (2, 128, 128)], (1, 128, 128), "unet_openai", bp, "datasets.lidc", vote, None)
+    model.unet.load_state_dict({k: torch.from_numpy(v) for k, v in make_synthetic_state_dict(model.unet.spec, 0).items()}, strict=True)
+    model = model.cuda().eval()
+    model.rng, model.philox_seed = rng_mode, 11
+    torch.manual_seed(123)
+    full = sample_sharded(model, x, img, t=torch.as_tensor(10004), gather=gather)
+    assert full.shape == (N, 2, 128, 128)
+    if rank == 0:
+        torch.manual_seed(123)
+        single = model(x, img, t=torch.as_tensor(10004))["diffusion_out"]
+        res[f"{vote}/{rng_mode}/{gather}"] = bool(torch.equal(full, single) and full.dtype == single.dtype)
+# differently seeded host generators must be refused in the parity mode
+model.rng = "torch_cpu"
+torch.manual_seed(1000 + rank)
+try:
+    sample_sharded(model, x, img, t=torch.as_tensor(10002))
+    res["rng_check"] = False
+except RuntimeError as e:
+    res["rng_check"] = "different states" in str(e)
+dist.barrier(); dist.destroy_process_group()
+if rank == 0:
+    sys.stdout.write("RESULT " + json.dumps(res) + "\n"); sys.stdout.flush()
+"""
+
+
+def test_two_ranks_of_the_real_model_reproduce_the_single_process_run(U, tmp_path):
+    """torch.distributed with two ranks of the real DenoisingModel (both on cuda:0, gloo for the final gather; RCCL needs two
+    GPUs): the gathered predictions equal the single-process run bit-for-bit — fp32 probabilities, the uint8-index gather of
+    one-hot "majority" outputs, and the host-noise parity mode (each rank draws the full batch and slices its rows)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "ranks_worker.py"
+    script.write_text(RANKS_WORKER)
+    env = dict(os.environ, CCDM_ROOT=root, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29641", str(script)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+    res = json.loads(line[len("RESULT "):])
+    assert res and all(res.values()), res
+
+
+# ------------------------------------------------------------------------------------------ N2 harness vs the reference's Tester
+@pytest.mark.parametrize("vote", ["confidence", "majority"])
+def test_lidc_harness_numbers_match_reference_tester(U, golden, vote):
+    """eval_lidc_uncertainty around a stand-in model that returns fixed seeded predictions, against G14: the numbers the
+    reference's own Tester.test_step accumulates on the same batches and predictions (tools/gen_goldens_harness.py) — GED,
+    diversities and Hungarian IoU to 1e-12, the confusion matrix behind IoU / mIoU / Dice exactly (incl. the log(0) vote of
+    one-hot "majority" predictions)."""
+    from ccdm_stochastic_segmentation_amd import evaluation as E
+    from tests.golden_util import harness_case
+    g = golden["g14_lidc_harness"]
+    batches, evaluations, K, predict = harness_case(vote)
+
+    class DS(torch.utils.data.Dataset):
+        items = [(b[0][i], b[1][i], b[2][i]) for b in batches for i in range(b[0].shape[0])]
+
+        def __len__(self):
+            return len(self.items)
+
+        def __getitem__(self, i):
+            return self.items[i]
+
+    class Fake:
+        step_T_sample = vote
+        calls = 0
+
+        def __call__(self, x, image, **kw):
+            assert x.is_cuda and image.is_cuda and x.shape[0] == image.shape[0]
+            p = predict(Fake.calls, x.shape[0]).to(x.device)
+            Fake.calls += 1
+            return {"diffusion_out": p}
+
+    res = E.eval_lidc_uncertainty({"dataset_file": "datasets.lidc", "batch_size": 2, "evaluations": evaluations}, dataset=DS(), device="cuda:0",
+                                  model=Fake())
+    assert res["images"] == int(g[f"{vote}_n_img"])
+    np.testing.assert_allclose(res["GED"], g[f"{vote}_geds"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(res["diversity_samples"], g[f"{vote}_div_samples"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(res["diversity_experts"], g[f"{vote}_div_experts"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(res["HM_IoU"], g[f"{vote}_hm_ious"], rtol=0, atol=1e-12)
+    assert res["nonzero"] == int(g[f"{vote}_nonzero"]) / (res["images"] * 4)
+    cm = g[f"{vote}_conf"].astype(np.float64)
+    iou = np.diag(cm) / (cm.sum(1) + cm.sum(0) - np.diag(cm) + 1e-15)
+    dice = 2 * np.diag(cm) / (cm.sum(1) + cm.sum(0) + 1e-15)
+    np.testing.assert_allclose(res["IoU"], iou, rtol=0, atol=1e-15)
+    np.testing.assert_allclose(res["Dice"], dice, rtol=0, atol=1e-15)
+    assert abs(res["mIoU"] - iou.mean()) < 1e-15

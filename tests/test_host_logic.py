@@ -266,3 +266,150 @@ def test_ddpm_eval_dispatch(tmp_path, monkeypatch):
     yaml.safe_dump(p, open(f, "w"))
     with pytest.raises(NotImplementedError):
         ddpm_eval.main(["ddpm_eval.py", str(f)])
+
+
+def test_lidc_reader_layout_and_transform(tmp_path):
+    """`Test_LIDC` + `batch_transform` (datasets/lidc.py:164-210) on a data_lidc.hdf5-layout source: images [n,128,128] float in
+    [-0.5, 0.5] -> [1,128,128] * 2; labels [n,4,128,128] -> [4,2,128,128] one-hot floats; max_size caps the split.  The mapping
+    form runs everywhere; the same data written to a real HDF5 file is read back when h5py is installed."""
+    from ccdm_stochastic_segmentation_amd import evaluation as E
+    rng = np.random.default_rng(3)
+    images = rng.uniform(-0.5, 0.5, (5, 128, 128)).astype(np.float32)
+    labels = (rng.random((5, 4, 128, 128)) > 0.7).astype(np.uint8)
+    src = {"test": {"images": images, "labels": labels}}
+    ds = E.TestLIDC(src, "test", None)
+    assert len(ds) == 5 and len(E.TestLIDC(src, "test", 3)) == 3 and len(E.TestLIDC(src, "test", 500)) == 5
+    img, lab, w = ds[2]
+    assert img.shape == (1, 128, 128) and img.dtype == torch.float32 and torch.equal(img[0], torch.from_numpy(images[2]) * 2)
+    assert lab.shape == (4, 2, 128, 128) and lab.dtype == torch.float32 and torch.equal(lab.argmax(1), torch.from_numpy(labels[2]).long())
+    assert torch.equal(lab.sum(1), torch.ones(4, 128, 128)) and list(w) == [0.25] * 4
+    # dataset_val_max_size: null (the shipped params_eval.yml) = the whole split, as the reference's test_dataset(None)
+    import yaml
+    p = yaml.safe_load(open(os.path.join(ROOT, "params_eval.yml")))
+    assert p["dataset_val_max_size"] is None
+    try:
+        import h5py
+    except ImportError:
+        pytest.skip("h5py is not installed in this image: the HDF5 file form of the reader cannot run here")
+    f = tmp_path / "data_lidc.hdf5"
+    with h5py.File(f, "w") as h:
+        gtest = h.create_group("test")
+        gtest.create_dataset("images", data=images)
+        gtest.create_dataset("labels", data=labels)
+    ds2 = E.make_dataset({"dataset_file": "datasets.lidc", "dataset_path": str(f), "dataset_val_max_size": 4})
+    assert len(ds2) == 4 and torch.equal(ds2[2][0], img) and torch.equal(ds2[2][1], lab)
+
+
+class _NotATensor:                    # stands for an arbitrary class inside a checkpoint (module level: picklable)
+    pass
+
+
+def test_checkpoint_reader_refuses_unsafe_pickle_without_opt_in(tmp_path, monkeypatch):
+    from ccdm_stochastic_segmentation_amd import evaluation as E
+
+    m = lidc_model()
+    sd = {k: torch.from_numpy(v) for k, v in P.make_synthetic_state_dict(m.unet.spec, 0).items()}
+    good = tmp_path / "good.pt"
+    torch.save({"model": sd, "average_model": sd}, good)
+    E.load_checkpoint(m, str(good))
+    assert torch.equal(m.unet.state_dict()["out.2.weight"], sd["out.2.weight"])
+    bad = tmp_path / "bad.pt"
+    torch.save({"average_model": sd, "engine": _NotATensor()}, bad)
+    monkeypatch.delenv("CCDM_ALLOW_UNSAFE_PICKLE", raising=False)
+    with pytest.raises(RuntimeError, match="allow_pickle"):
+        E.load_checkpoint(m, str(bad))
+    E.load_checkpoint(m, str(bad), allow_pickle=True)
+
+
+def test_sampler_options_from_params_file():
+    from ccdm_stochastic_segmentation_amd import evaluation as E
+    m = lidc_model()
+    assert m.prec == hip.PREC_F16X3 and m.rng == "philox"            # the defaults ARE the benchmarked configuration
+    E.apply_sampler_options(m, {})
+    assert m.prec == hip.PREC_F16X3 and m.rng == "philox" and m.on_range_error == "f32"
+    E.apply_sampler_options(m, {"prec": "f32", "rng": "torch_cpu", "philox_seed": 9, "substreams": 2})
+    assert m.prec == hip.PREC_F32 and m.rng == "torch_cpu" and m.philox_seed == 9 and m.substreams == 2
+    with pytest.raises(ValueError, match="prec"):
+        E.apply_sampler_options(m, {"prec": "bf16"})
+
+
+def test_weights_key_sees_in_place_updates():
+    m = lidc_model()
+    k0 = m._weights_key()
+    with torch.no_grad():
+        next(m.unet.parameters()).mul_(1.0)                          # optimizer step / Polyak update style
+    k1 = m._weights_key()
+    assert k1 != k0
+    with torch.no_grad():
+        m.unet.state_dict()["out.2.bias"].copy_(torch.ones(2))       # p.data.copy_ style
+    assert m._weights_key() != k1
+
+
+def test_feature_condition_on_an_unwired_model_fails_like_the_reference():
+    """target_layer / output_stride that do not line up: the reference builds the model and fails on the channel mismatch when a
+    feature tensor is passed; a model without any feature encoder ignores the tensor."""
+    fce = dict(type="dino", channels=384, output_stride=4, scale="single", target_layer=10)       # block 10 sits at stride 8
+    m = P.build_model(250, "cosine", None, [(3, 64, 128), (20, 64, 128)], (3, 64, 128), "unet_openai",
+                      dict(LIDC_BP, channel_mult=[1, 1, 2, 2, 4, 4]), "datasets.cityscapes", "confidence", fce).eval()
+    assert m.unet.spec.feature_condition_unwired == [10] and not m.unet.spec.feature_condition_idx
+    x = torch.zeros(1, 20, 64, 128); x[:, 0] = 1
+    with pytest.raises(RuntimeError, match="channel mismatch"):
+        m(x, torch.zeros(1, 3, 64, 128), torch.zeros(1, 384, 8, 16))
+
+
+def test_bench_self_launch_command(monkeypatch):
+    """`python bench.py --gpus N` without a launcher environment starts its own ranks with torch.distributed.run."""
+    import bench
+    seen = {}
+    monkeypatch.setattr(bench.subprocess, "call", lambda cmd, env=None: seen.update(cmd=cmd, env=env) or 0)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2", "--warmup", "1"])
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "2", "--warmup", "1"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_host_noise_is_drawn_in_bounded_blocks(monkeypatch):
+    """rng='torch_cpu': the per-step Exp(1) draws are consumed from torch's generator in the reference's order whatever the block
+    size, and no more than one block is resident (checked on the host logic with a stub engine)."""
+    from ccdm_stochastic_segmentation_amd import models as Mo
+    m = lidc_model().eval()
+    m.rng = "torch_cpu"
+    calls = []
+
+    class Eng:
+        device = torch.device("cpu"); stream = None; H = W = 8; K = 2
+        def __init__(self, n): self.N = n; self.xt = torch.zeros(n, 64, dtype=torch.uint8); self.out_probs = torch.zeros(n, 8, 8, 2)
+        def enter(self):
+            import contextlib; return contextlib.nullcontext()
+        def leave(self): pass
+        def set_inputs(self, *a): pass
+        def set_tables(self, *a): pass
+        def raise_if_flagged(self): pass
+        def run(self, n_steps, *, first_row, noise, noise_row0, **kw):
+            calls.append((first_row, n_steps, noise_row0, None if noise is None else noise.clone()))
+    monkeypatch.setattr(Mo.DenoisingModel, "_engine", lambda self, x, c, f, slot=0: Eng(x.shape[0]))
+    monkeypatch.setattr(torch.cuda, "stream", lambda s: __import__("contextlib").nullcontext())
+    x = torch.zeros(3, 2, 8, 8); x[:, 0] = 1
+    cond = torch.zeros(3, 1, 8, 8)
+    per_step = 3 * 8 * 8 * 2 * 4
+    outs = []
+    for blk_steps in (1000, 2):
+        monkeypatch.setattr(Mo, "HOST_NOISE_BLOCK_BYTES", blk_steps * per_step)
+        calls.clear()
+        torch.manual_seed(5)
+        m._forward_denoising(x, cond, None, init_t=5)               # steps t = 5,4,3,2 draw; t = 1 does not
+        outs.append([c for c in calls])
+    assert [(c[0], c[1], c[2]) for c in outs[0]] == [(0, 5, 0)]
+    assert [(c[0], c[1], c[2]) for c in outs[1]] == [(0, 2, 0), (2, 2, 2), (4, 1, 4)]
+    whole = outs[0][0][3]
+    assert max(c[3].numel() for c in outs[1]) <= 2 * 3 * 128
+    assert torch.equal(torch.cat([c[3] for c in outs[1]], 0)[:4], whole[:4])          # same generator order, block by block
+    torch.manual_seed(5)
+    ref = torch.stack([torch.empty(3 * 64, 2).exponential_(1).reshape(3, 128) for _ in range(4)])
+    assert torch.equal(whole[:4], ref)
