@@ -106,25 +106,6 @@ def self_launch(args) -> int:
     return subprocess.call(cmd, env=env)
 
 
-def op_roofline(info, n, mean_ms, prec_f16x3):
-    """roofline object of one tapped launch: algorithmic bytes of op `info` at n samples over its mean duration."""
-    conv_io, gn, wts = info["io_bytes"] * n, info["gn_read_bytes"] * n, info["weight_bytes"]
-    total = conv_io + gn + wts
-    ach = total / (mean_ms * 1e-3) / 1e9
-    flop = info["flop"] * n
-    r = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-         "avg_launch_ms": mean_ms, "algorithmic_bytes_per_launch": total, "samples_per_launch": n,
-         "achieved_conv_io_only": (conv_io + wts) / (mean_ms * 1e-3) / 1e9,
-         "frac_conv_io_only": (conv_io + wts) / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-         "algorithmic_tflops": flop / (mean_ms * 1e-3) / 1e12,
-         # matrix-pipe utilisation from the instruction count: every fp32 product is 3 fp16 MFMA products (hi*hi, hi*lo, lo*hi),
-         # so the matrix cores execute 3x the algorithmic FLOPs; relative to the dense fp16 peak at the 2.4 GHz top clock
-         # (the PMC figure SQ_VALU_MFMA_BUSY_CYCLES / total SIMD cycles is in profiles/)
-         "mfma_util": (3.0 if prec_f16x3 else 16.0) * flop / (mean_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
-         "mfma_util_source": "analytic: MFMA FLOPs issued (3 fp16 products per fp32 product) / HIP-event duration / 2.5 PFLOP/s dense"}
-    return r
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -201,21 +182,16 @@ def main():
     nsub = max(1, min(args.substreams, n))
     n_tap = n // nsub
     eng = model._engine(x[:n_tap], image[:n_tap], feat[:n_tap] if feat is not None else None, slot=0)
-    conv_ops = [i for i, o in enumerate(eng.op_info) if o["kind"] == "conv" and o["k"] == 3 and o["gn"]]
-    # dominant shape = the (cin, cout, size) group of GN+SiLU 3x3 convs with the largest FLOP share of the step (C2: the eight
-    # 32->32 @128x128 launches, 29.6 %); heaviest = the single longest launch by algorithmic bytes (C2: decoder 64->32 @128x128)
-    groups = {}
-    for i in conv_ops:
-        o = eng.op_info[i]
-        if not o["skip"]:
-            groups.setdefault((o["cin"], o["cout"], o["hout"], o["wout"], o["stride"], o["up"]), []).append(i)
-    dom_key = max(groups, key=lambda k_: sum(eng.op_info[i]["flop"] for i in groups[k_]))
-    dom = groups[dom_key][0]
-    heavy = max(conv_ops, key=lambda i: eng.op_info[i]["io_bytes"] + eng.op_info[i]["gn_read_bytes"])
-    attn_ops = [i for i, o in enumerate(eng.op_info) if o["kind"] == "attention" and o["T"] >= 2048]
-    attn = max(attn_ops, key=lambda i: eng.op_info[i]["T"]) if attn_ops else None
+    # The dominant kernel = the conv instantiation of the full-resolution stage: every 3x3 stride-1 conv whose output is HxW runs
+    # the same k_conv<...> symbol on the same grid (C2: 13 launches per denoise step, 42 % of its time) — the unit rocprofv3's
+    # per-kernel statistics report.  All of its launches are tapped; `roofline` is their aggregate (sum of algorithmic bytes
+    # over sum of durations), `roofline_shapes` splits it by layer shape.
+    info = eng.op_info
+    dom_ops = [i for i, o in enumerate(info) if o["kind"] == "conv" and o["k"] == 3 and o["stride"] == 1 and (o["hout"], o["wout"]) == (H, W)]
+    attn_ops = [i for i, o in enumerate(info) if o["kind"] == "attention" and o["T"] >= 2048]
+    attn = max(attn_ops, key=lambda i: info[i]["T"]) if attn_ops else None
     taps = not args.graph
-    tapped = [i for i in dict.fromkeys([dom, heavy, attn]) if i is not None]
+    tapped = dom_ops + ([attn] if attn is not None else [])
     if taps:
         for i in tapped:
             eng.profile_op(i, capacity=n_dsteps)          # HIP events around that launch, on the engine's stream
@@ -225,6 +201,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     kern = {i: [] for i in tapped}
+    info = eng.op_info
     for _ in range(args.steps):
         out = one_pass()
         if taps:
@@ -269,33 +246,48 @@ def main():
                                 "algorithmic_tflops": cfg["gflop"] * n / ms_dstep, "mfma_util": (3.0 if f16 else 16.0) * cfg["gflop"] * n / ms_dstep / MFMA_PEAK_TFLOPS}
         res["roofline"] = None
         if taps:
-            m_dom, c_dom = mean_ms(dom)
-            if c_dom:
-                r = op_roofline(eng.op_info[dom], n_tap, m_dom, f16)
-                traffic, src = None, None
-                pmc = os.path.join(ROOT, "profiles", "r01_pmc_dominant_kernel.json")
-                if args.config in ("c2", "c3shard") and f16 and os.path.exists(pmc):
-                    # NOT measured in this run: HBM bytes per launch of this shape from committed rocprofv3 --pmc passes
-                    # (2 x FETCH_SIZE + WRITE_SIZE, KiB, separate passes, per MI355X_MICROARCH.md) at 64 samples per launch,
-                    # scaled by samples per launch (every byte is per-sample work)
-                    pj = json.load(open(pmc))
-                    traffic, src = pj.get("hbm_bytes") * n_tap / 64, "offline PMC constant (profiles/r01_pmc_dominant_kernel.json), not collected in this run"
-                o = eng.op_info[dom]
-                r.update({"traffic": traffic, "traffic_source": src, "launches_timed": c_dom, "concurrent_streams": nsub,
-                          "launches_per_denoise_step": len(groups[dom_key]),
-                          "kernel": f"ccdm::k_conv (engine op {dom}, {eng.op_names[dom]}: conv3x3 {o['cin']}->{o['cout']} @{o['hout']}x{o['wout']}, GN+SiLU on load)"})
-                res["roofline"] = r
-            m_h, c_h = mean_ms(heavy)
-            if c_h and heavy != dom:
-                o = eng.op_info[heavy]
-                r = op_roofline(o, n_tap, m_h, f16)
-                r.update({"launches_timed": c_h, "kernel": f"ccdm::k_conv (engine op {heavy}, {eng.op_names[heavy]}: conv3x3 {o['cin']}->{o['cout']} @{o['hout']}x{o['wout']}, "
-                                                           "GN+SiLU on load; the longest single launch of the step)"})
-                res["roofline_heaviest"] = r
+            per = {i: mean_ms(i) for i in dom_ops}
+            if all(c for _, c in per.values()):
+                tot_ms = sum(m for m, _ in per.values())
+                bytes_all = sum(info[i]["io_bytes"] * n_tap + info[i]["gn_read_bytes"] * n_tap + info[i]["weight_bytes"] for i in dom_ops)
+                bytes_io = sum(info[i]["io_bytes"] * n_tap + info[i]["weight_bytes"] for i in dom_ops)
+                flop = sum(info[i]["flop"] * n_tap for i in dom_ops)
+                ach = bytes_all / (tot_ms * 1e-3) / 1e9
+                shapes = {}
+                for i in dom_ops:
+                    o = info[i]
+                    key = f"{o['cin']}->{o['cout']}" + (" +fused 1x1 skip" if o["skip"] else "") + (" up2x" if o["up"] else "") + ("" if o["gn"] else " (no GroupNorm)")
+                    sh = shapes.setdefault(key, dict(launches_per_denoise_step=0, ms=0.0, bytes=0, bytes_io=0, flop=0, ops=[]))
+                    sh["launches_per_denoise_step"] += 1
+                    sh["ms"] += per[i][0]
+                    sh["bytes"] += o["io_bytes"] * n_tap + o["gn_read_bytes"] * n_tap + o["weight_bytes"]
+                    sh["bytes_io"] += o["io_bytes"] * n_tap + o["weight_bytes"]
+                    sh["flop"] += o["flop"] * n_tap
+                    sh["ops"].append(i)
+                res["roofline"] = {
+                    "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "traffic": None, "traffic_source": "PMC passes are collected off-line (profiles/): HBM counters cannot be read inside the timed run",
+                    "kernel": f"ccdm::k_conv<F16X3,16,3,1,8,32,4,2,1,1> (<PREC,CK,KS,STRIDE,TH,TW,WAVES,MI,NI,KSP>): every 3x3 stride-1 conv of the {H}x{W} stage "
+                              f"(engine ops {dom_ops}), GN+SiLU on load" if f16 else f"ccdm::k_conv<F32,...> every 3x3 stride-1 conv of the {H}x{W} stage (engine ops {dom_ops})",
+                    "launches_per_denoise_step": len(dom_ops), "avg_launch_ms": tot_ms / len(dom_ops), "launches_timed": sum(c for _, c in per.values()),
+                    "algorithmic_bytes_per_launch": bytes_all / len(dom_ops), "samples_per_launch": n_tap, "concurrent_streams": nsub,
+                    "achieved_conv_io_only": bytes_io / (tot_ms * 1e-3) / 1e9, "frac_conv_io_only": bytes_io / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "share_of_denoise_step": tot_ms / ms_dstep,
+                    "algorithmic_tflops": flop / (tot_ms * 1e-3) / 1e12,
+                    # matrix-pipe utilisation from the instruction count: every fp32 product is 3 fp16 MFMA products (hi*hi, hi*lo, lo*hi);
+                    # relative to the dense fp16 peak at the top clock (the PMC figure SQ_VALU_MFMA_BUSY_CYCLES is in profiles/)
+                    "mfma_util": (3.0 if f16 else 16.0) * flop / (tot_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
+                    "mfma_util_source": "analytic: MFMA FLOPs issued (3 fp16 products per fp32 product) / HIP-event duration / 2.5 PFLOP/s dense",
+                }
+                res["roofline_shapes"] = {
+                    k_: {"launches_per_denoise_step": v["launches_per_denoise_step"], "avg_launch_ms": v["ms"] / v["launches_per_denoise_step"],
+                         "frac": v["bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "frac_conv_io_only": v["bytes_io"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "mfma_util": (3.0 if f16 else 16.0) * v["flop"] / (v["ms"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "engine_ops": v["ops"]}
+                    for k_, v in shapes.items()}
             if attn is not None:
                 m_a, c_a = mean_ms(attn)
                 if c_a:
-                    o = eng.op_info[attn]
+                    o = info[attn]
                     fl = o["flop"] * n_tap
                     res["roofline_attention"] = {
                         "bound": "mfma", "achieved": fl / (m_a * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -314,13 +306,14 @@ def main():
         for i, o in enumerate(eng.op_info):
             cnt, m, lo, hi = eng.profile_read(i)
             per_op.append(dict(op=i, name=o["name"], kind=o["kind"], mean_us=m * 1e3, min_us=lo * 1e3, max_us=hi * 1e3,
-                               shape=(f"{o['cin']}->{o['cout']} k{o['k']} @{o['hout']}x{o['wout']}" if o["kind"] == "conv" else f"T={o['T']} C={o['C']}"),
+                               shape=(f"{o['cin']}->{o['cout']} k{o['k']} @{o['hout']}x{o['wout']}" if o["kind"] == "conv" else
+                                      (f"T={o['T']} C={o['C']}" if "T" in o else "")),
                                hbm_frac=(o["io_bytes"] * n + o["gn_read_bytes"] * n + o["weight_bytes"]) / max(m, 1e-9) / 1e6 / HBM_PEAK_GBS))
         eng.profile_op(-1)
         by_stage = {}
         for p in per_op:
             o = eng.op_info[p["op"]]
-            key = f"{o['hout']}x{o['wout']}" if o["kind"] == "conv" else "attention"
+            key = f"{o['hout']}x{o['wout']}" if o["kind"] == "conv" else o["kind"]
             by_stage[key] = by_stage.get(key, 0.0) + p["mean_us"]
         res["per_stage_us"] = {k_: round(v, 1) for k_, v in by_stage.items()}
         res["per_stage_note"] = "sum of per-op mean launch times (HIP events around every op, one extra untimed pass) grouped by output size"

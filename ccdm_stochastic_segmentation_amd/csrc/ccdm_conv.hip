@@ -849,11 +849,15 @@ static int launch_prec(const ConvK& k, const ConvGeo& g, int NI, int ck, dim3 gr
 int conv_slices(int Hout, int Wout, int stride) {
     const ConvGeo g = conv_geo(Hout, Wout, stride);
     const int tiles = cdiv(Hout, g.TH) * cdiv(Wout, g.TW);
-    // 12 slices for big images: with 3 resident blocks per CU, 64 samples x 12 slices = 768 blocks fill the 256 CUs
-    // in exactly one round.  A function of the spatial size only (never of N): sharding the batch must not change
-    // the order in which statistics partials are added.
+    // 12 slices for 128x128: with 3 resident blocks per CU, 64 samples x 12 slices = 768 blocks fill the 256 CUs
+    // in exactly one round (5.3 tiles per block).  Larger images keep that work per block — one slice per 5.3 tiles (256x512:
+    // 96, 512x1024: 384) — so a Cityscapes-sized batch of 4-16 samples still fills the chip (at 12 slices, 4 samples were
+    // 48 blocks on 256 CUs).  More than CCDM_STATS_MAX_SLICES partials are folded to 16 by ccdm_stats_fold before a GroupNorm
+    // reads them.  A function of the spatial size only (never of N): sharding the batch must not change the order in which
+    // statistics partials are added.
     static const int ovr = getenv("CCDM_SLICES") ? atoi(getenv("CCDM_SLICES")) : 0;     // experiment hook
     if (ovr > 0 && ovr <= CCDM_STATS_MAX_SLICES && tiles >= ovr) return ovr;
+    if (tiles >= 128) return tiles / 16 * 3;
     if (tiles >= 48) return 12;
     if (tiles >= 16) return 8;       // 64x64: 8 slices x 2 tiles (512 blocks, all resident) 28.8 us vs 16 x 1 (1024 blocks, a thin second round) 30.7
     return tiles < CCDM_STATS_MAX_SLICES ? tiles : CCDM_STATS_MAX_SLICES;

@@ -14,10 +14,21 @@ __global__ void k_step_set(int32_t* p, int32_t v) { *p = v; }
 __global__ void k_step_inc(int32_t* p) { *p += 1; }
 
 struct Op {
-    int kind;   // 0 conv, 1 attention
+    int kind;   // 0 conv, 1 attention core, 2 statistics fold, 3 GroupNorm + qkv + attention core
     ccdm_conv_args conv;
     const float* qkv; float* out; int N, T, C, heads, order;
+    const double* fin; double* fout; int S_in, S_out;
+    ccdm_attn_block_args ab;
 };
+
+static int launch_op(const Op& op, hipStream_t s) {
+    switch (op.kind) {
+        case 0: return launch_conv(op.conv, s);
+        case 1: return launch_attention(op.qkv, op.out, op.N, op.T, op.T, op.C, op.heads, op.order, s);
+        case 2: return launch_stats_fold(op.fin, op.N, op.S_in, op.C, op.S_out, op.fout, s);
+        default: return launch_attn_block(op.ab, s);
+    }
+}
 
 }  // namespace ccdm
 
@@ -53,8 +64,7 @@ static int launch_step(ccdm_engine* e, int with_epilogue, hipStream_t s, bool pr
             if (it != e->taps.end() && (size_t)(2 * it->second.n + 1) < it->second.ev.size()) tp = &it->second;
         }
         if (tp) (void)hipEventRecord(tp->ev[2 * tp->n], s);
-        int rc = op.kind == 0 ? launch_conv(op.conv, s)
-                              : launch_attention(op.qkv, op.out, op.N, op.T, op.T, op.C, op.heads, op.order, s);
+        int rc = launch_op(op, s);
         if (tp) { (void)hipEventRecord(tp->ev[2 * tp->n + 1], s); tp->n++; }
         if (rc) return rc;
     }
@@ -98,6 +108,27 @@ extern "C" int ccdm_engine_add_attention(ccdm_engine* e, const float* qkv, float
     Op op{};
     op.kind = 1;
     op.qkv = qkv; op.out = out; op.N = N; op.T = T; op.C = C; op.heads = heads; op.order = order;
+    e->ops.push_back(op);
+    drop_graph(e);
+    return (int)e->ops.size() - 1;
+}
+
+extern "C" int ccdm_engine_add_norm_qkv_attention(ccdm_engine* e, const ccdm_attn_block_args* a) {
+    CCDM_REQUIRE(e && a, "engine_add_norm_qkv_attention: null");
+    CCDM_REQUIRE(attn_block_supported(a->T, a->C, a->heads), "engine_add_norm_qkv_attention: (T=%d, C=%d, heads=%d) is not built", a->T, a->C, a->heads);
+    Op op{};
+    op.kind = 3;
+    op.ab = *a;
+    e->ops.push_back(op);
+    drop_graph(e);
+    return (int)e->ops.size() - 1;
+}
+
+extern "C" int ccdm_engine_add_stats_fold(ccdm_engine* e, const double* in, int N, int S_in, int C, int S_out, double* out) {
+    CCDM_REQUIRE(e && in && out, "engine_add_stats_fold: null");
+    Op op{};
+    op.kind = 2;
+    op.fin = in; op.fout = out; op.N = N; op.S_in = S_in; op.C = C; op.S_out = S_out;
     e->ops.push_back(op);
     drop_graph(e);
     return (int)e->ops.size() - 1;
@@ -213,8 +244,12 @@ extern "C" int ccdm_engine_describe_op(const ccdm_engine* e, int i, char* buf, i
                  a.C1 ? "(cat)" : "", a.Cout, a.Hin, a.Win, a.Hout, a.Wout, a.stride, a.up ? " up2x" : "",
                  a.stats0 ? " gn" : "", a.act ? " silu" : "", a.emb_off >= 0 ? " +emb" : "", a.resid ? " +res" : "",
                  a.out_stats ? " stats" : "");
-    } else {
+    } else if (op.kind == 1) {
         snprintf(buf, buflen, "attention T=%d C=%d heads=%d order=%d", op.T, op.C, op.heads, op.order);
+    } else if (op.kind == 2) {
+        snprintf(buf, buflen, "stats fold %d -> %d slices, C=%d", op.S_in, op.S_out, op.C);
+    } else {
+        snprintf(buf, buflen, "norm+qkv+attention T=%d C=%d heads=%d", op.ab.T, op.ab.C, op.ab.heads);
     }
     return 0;
 }

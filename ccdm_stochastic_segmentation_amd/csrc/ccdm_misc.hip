@@ -228,6 +228,34 @@ using namespace ccdm;
 extern "C" int ccdm_version(void) { return CCDM_ABI_VERSION; }
 extern "C" const char* ccdm_last_error_string(void) { return g_err.c_str(); }
 
+// Fold S_in statistics slices into S_out <= CCDM_STATS_MAX_SLICES: out slice j = in slices [j*S_in/S_out, (j+1)*S_in/S_out)
+// added in ascending order (fixed order: deterministic, independent of the batch size).
+namespace ccdm {
+__global__ void k_stats_fold(const double* __restrict__ in, int S_in, int C2, int S_out, double* __restrict__ out) {
+    const int n = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;        // (out slice, channel*2 + {sum, sumsq})
+    if (i >= S_out * C2) return;
+    const int j = i / C2, c = i % C2;
+    const int s0 = (int)((long long)j * S_in / S_out), s1 = (int)((long long)(j + 1) * S_in / S_out);
+    const double* p = in + (size_t)n * S_in * C2 + c;
+    double t = 0.0;
+    for (int s = s0; s < s1; ++s) t += p[(size_t)s * C2];
+    out[(size_t)n * S_out * C2 + i] = t;
+}
+int launch_stats_fold(const double* in, int N, int S_in, int C, int S_out, double* out, hipStream_t s) {
+    CCDM_REQUIRE(in && out && N > 0 && C > 0, "stats_fold: bad arguments");
+    CCDM_REQUIRE(S_out >= 1 && S_out <= CCDM_STATS_MAX_SLICES && S_in >= S_out, "stats_fold: %d -> %d slices", S_in, S_out);
+    dim3 grid((unsigned)cdiv(S_out * C * 2, 256), (unsigned)N);
+    hipLaunchKernelGGL(k_stats_fold, grid, dim3(256), 0, s, in, S_in, 2 * C, S_out, out);
+    CCDM_CHECK_LAUNCH("stats_fold");
+    return 0;
+}
+}  // namespace ccdm
+
+extern "C" int ccdm_stats_fold(const double* in, int N, int S_in, int C, int S_out, double* out, void* stream) {
+    return ccdm::launch_stats_fold(in, N, S_in, C, S_out, out, (hipStream_t)stream);
+}
+
 extern "C" int ccdm_gn_stats(const float* x, int N, int HW, int C, int slices, double* stats, void* stream) {
     CCDM_REQUIRE(x && stats, "gn_stats: null pointer");
     CCDM_REQUIRE(C % 4 == 0 && C >= 4 && C <= 1024, "gn_stats: C=%d must be a multiple of 4 in [4,1024]", C);

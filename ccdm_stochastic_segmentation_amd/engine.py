@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -96,6 +97,18 @@ class SamplerEngine:
             t.stats = self._dev((self.N, t.slices, C_, 2), torch.float64)
         return t
 
+    def _fold_stats(self, t: DevTensor) -> None:
+        """Large images: the conv leaves one statistics slice per workgroup (up to 384 per sample); a GroupNorm consumer reads at
+        most STATS_MAX_SLICES, so fold them right behind the producer (fixed order, independent of N)."""
+        if t.stats is None or t.slices <= hip.STATS_MAX_SLICES:
+            return
+        folded = self._dev((self.N, hip.STATS_MAX_SLICES, t.C, 2), torch.float64)
+        hip.check(self.lib.ccdm_engine_add_stats_fold(self._handle, t.stats.data_ptr(), self.N, t.slices, t.C, hip.STATS_MAX_SLICES,
+                                                      folded.data_ptr()), "engine_add_stats_fold")
+        self.op_names.append("stats_fold")
+        self.op_info.append(dict(kind="stats_fold", name="stats_fold", io_bytes=0, gn_read_bytes=0, weight_bytes=0, flop=0))
+        t.stats, t.slices = folded, hip.STATS_MAX_SLICES
+
     # ------------------------------------------------------------------ op emission
     def _conv(self, src: Sequence[DevTensor], wkey: str, cout: int, ksize: int, *, gn: Optional[str] = None,
               act: int = hip.ACT_NONE, stride: int = 1, up: bool = False, emb_off: int = -1,
@@ -169,6 +182,7 @@ class SamplerEngine:
         self.op_info.append(dict(kind="conv", name=wkey, cin=cin, cout=cout, k=ksize, hin=hin, win=win, hout=hout, wout=wout,
                                  stride=stride, up=bool(up), gn=gn is not None, skip=skip_src is not None,
                                  io_bytes=io, gn_read_bytes=(4 * cin * hin * win if gn is not None else 0), weight_bytes=wbytes, flop=flop))
+        self._fold_stats(out)
         return out
 
     def _res(self, p: str, l, src: Sequence[DevTensor]) -> DevTensor:
@@ -187,12 +201,34 @@ class SamplerEngine:
                           film_off=off if l.film else -1, resid=src[0])
 
     def _attn(self, p: str, l, x: DevTensor) -> DevTensor:
+        T_ = x.h * x.w
+        fused = (self.prec == hip.PREC_F16X3 and x.stats is not None and not os.environ.get("CCDM_NO_ATTN_BLOCK")
+                 and self.lib.ccdm_norm_qkv_attention_supported(T_, l.ch, l.heads))
+        if fused:
+            # GroupNorm + qkv + attention core in one launch (low-resolution stages): the 3C-wide qkv tensor stays on chip
+            sd = self._sd
+            wq, bq = hip.pack_qkv_weights(sd[p + ".qkv.weight"].numpy(), sd[p + ".qkv.bias"].numpy(), l.heads, bool(l.new_order))
+            att = self._act(l.ch, x.h, x.w, False)
+            a = hip.AttnBlockArgs()
+            a.x, a.stats, a.slices = x.ptr, x.stats_ptr, x.slices
+            a.gamma = self._upload(sd[p + ".norm.weight"].numpy()).data_ptr()
+            a.beta = self._upload(sd[p + ".norm.bias"].numpy()).data_ptr()
+            a.eps = GN_EPS
+            a.wqkv, a.bqkv = self._upload(wq).data_ptr(), self._upload(bq).data_ptr()
+            a.out = att.ptr
+            a.N, a.T, a.C, a.heads = self.N, T_, l.ch, l.heads
+            hip.check(self.lib.ccdm_engine_add_norm_qkv_attention(self._handle, C.byref(a)), "engine_add_norm_qkv_attention " + p)
+            self.op_names.append(p + ".norm_qkv_attention")
+            C_ = l.ch
+            self.op_info.append(dict(kind="norm_qkv_attention", name=p + ".norm_qkv_attention", T=T_, C=C_, heads=l.heads,
+                                     io_bytes=4 * 8 * C_ * T_, gn_read_bytes=4 * C_ * T_, weight_bytes=4 * 3 * C_ * C_,
+                                     flop=2 * T_ * C_ * 3 * C_ + 4 * T_ * T_ * C_))
+            return self._conv([att], p + ".proj_out", l.ch, 1, resid=x)
         qkv = self._conv([x], p + ".qkv", 3 * l.ch, 1, gn=p + ".norm", act=hip.ACT_NONE, stats=False)
         a = self._act(l.ch, x.h, x.w, False)
         hip.check(self.lib.ccdm_engine_add_attention(self._handle, qkv.ptr, a.ptr, self.N, x.h * x.w, l.ch, l.heads,
                                                      1 if l.new_order else 0), "engine_add_attention")
         self.op_names.append(p + ".attention")
-        T_ = x.h * x.w
         self.op_info.append(dict(kind="attention", name=p + ".attention", T=T_, C=l.ch, heads=l.heads, io_bytes=4 * 4 * l.ch * T_,
                                  gn_read_bytes=0, weight_bytes=0, flop=4 * T_ * T_ * l.ch))
         return self._conv([a], p + ".proj_out", l.ch, 1, resid=x)

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("CCDM_LIB") or os.path.join(_HERE, "libccdm_hip.so")      # CCDM_LIB: A/B two builds on one GPU box
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["ccdm_conv.hip", "ccdm_misc.hip", "ccdm_attention.hip", "ccdm_sampler.hip", "ccdm_metrics.hip", "ccdm_engine.hip"]
+SOURCES = ["ccdm_conv.hip", "ccdm_misc.hip", "ccdm_attention.hip", "ccdm_attn_block.hip", "ccdm_sampler.hip", "ccdm_metrics.hip", "ccdm_engine.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
 ACT_NONE, ACT_SILU = 0, 1
@@ -64,6 +64,17 @@ class PostArgs(C.Structure):
     ]
 
 
+class AttnBlockArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p),
+        ("stats", C.c_void_p), ("slices", C.c_int32),
+        ("gamma", C.c_void_p), ("beta", C.c_void_p), ("eps", C.c_float),
+        ("wqkv", C.c_void_p), ("bqkv", C.c_void_p),
+        ("out", C.c_void_p),
+        ("N", C.c_int32), ("T", C.c_int32), ("C", C.c_int32), ("heads", C.c_int32),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/ccdm_hip.h declares
 SIGNATURES = {
     "ccdm_version": (C.c_int, []),
@@ -71,6 +82,11 @@ SIGNATURES = {
     "ccdm_gn_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ccdm_conv_slices": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "ccdm_conv2d": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
+    "ccdm_stats_fold": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "ccdm_norm_qkv_attention_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "ccdm_norm_qkv_attention": (C.c_int, [C.POINTER(AttnBlockArgs), C.c_void_p]),
+    "ccdm_engine_add_norm_qkv_attention": (C.c_int, [C.c_void_p, C.POINTER(AttnBlockArgs)]),
+    "ccdm_engine_add_stats_fold": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ccdm_pack_conv_weight": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ccdm_pack_conv_weight_ex": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ccdm_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -208,3 +224,17 @@ def pack_conv_weight(w, ksize: int, prec: int = PREC_F32, cout_absmax=None):
     out = np.empty(nbytes, dtype=np.uint8)
     lib.ccdm_pack_conv_weight_ex(w.ctypes.data, cout, cin, ksize, prec, amp, out.ctypes.data)
     return out
+
+
+def pack_qkv_weights(qkv_w, qkv_b, heads: int, new_order: bool):
+    """AttentionBlock.qkv parameters -> the operands of ccdm_norm_qkv_attention (include/ccdm_hip.h): rows in legacy order
+    (head*96 + {q,k,v}*32 + d), packed as a 1x1 conv.  Returns (wqkv uint8, bqkv fp32) numpy arrays (host-side, no GPU needed)."""
+    import numpy as np
+    qkv_w = np.ascontiguousarray(qkv_w, dtype=np.float32).reshape(qkv_w.shape[0], -1)
+    C3, Cc = qkv_w.shape
+    assert C3 == 3 * Cc and Cc == heads * 32, (qkv_w.shape, heads)
+    qkv_b = np.ascontiguousarray(qkv_b, dtype=np.float32)
+    if new_order:          # channel = {q,k,v}*C + head*32 + d  ->  head*96 + {q,k,v}*32 + d
+        idx = np.array([j * Cc + h * 32 + d for h in range(heads) for j in range(3) for d in range(32)])
+        qkv_w, qkv_b = qkv_w[idx], qkv_b[idx]
+    return pack_conv_weight(qkv_w.reshape(C3, Cc, 1, 1), 1, PREC_F16X3), np.ascontiguousarray(qkv_b)

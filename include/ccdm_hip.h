@@ -24,7 +24,7 @@ extern "C" {
 
 #define CCDM_ABI_VERSION 2
 #define CCDM_MAX_CHANNELS 1024      /* max C0+C1 of a GroupNorm'ed conv input */
-#define CCDM_STATS_MAX_SLICES 16    /* partial-statistics slices per sample */
+#define CCDM_STATS_MAX_SLICES 16    /* partial-statistics slices per sample a GroupNorm consumer reads (more: ccdm_stats_fold) */
 
 int ccdm_version(void);
 const char* ccdm_last_error_string(void);
@@ -86,8 +86,12 @@ typedef struct ccdm_conv_args {
 } ccdm_conv_args;
 
 /* number of statistics slices the conv kernel produces for an Hout x Wout output (depends only on the
- * spatial size, never on N, so sharding the batch does not change any rounding) */
+ * spatial size, never on N, so sharding the batch does not change any rounding).  Large images yield more than
+ * CCDM_STATS_MAX_SLICES (one slice = one workgroup per sample: 256x512 -> 96, 512x1024 -> 384): fold them with
+ * ccdm_stats_fold before handing them to a GroupNorm consumer. */
 int ccdm_conv_slices(int Hout, int Wout, int stride, int ksize);
+/* out[n][j] = sum of in[n][i] over i in [j*S_in/S_out, (j+1)*S_in/S_out), ascending (fixed order); S_out <= CCDM_STATS_MAX_SLICES */
+int ccdm_stats_fold(const double* in /*dev [N,S_in,C,2]*/, int N, int S_in, int C, int S_out, double* out /*dev [N,S_out,C,2]*/, void* stream);
 int ccdm_conv2d(const ccdm_conv_args* a, void* stream);
 
 /* host-side weight packing.  `oihw` = reference layout [Cout,Cin,k,k] (conv2d) / [Cout,Cin,1] (conv1d).
@@ -104,6 +108,27 @@ size_t ccdm_pack_conv_weight_ex(const float* oihw, int Cout, int Cin, int ksize,
  * order 1 = QKVAttention        (channel = {q,k,v}*C + head*ch + c,   unet.py:376-395).
  * ------------------------------------------------------------------------------------------------- */
 int ccdm_attention(const float* qkv, float* out, int N, int T, int C, int heads, int order, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * First half of an AttentionBlock in one launch, for the low-resolution stages:
+ *     a = attention(qkv(GroupNorm32(x)))                                          unet.py:291-311, core :343-360 / :376-395
+ * One workgroup per (sample, head): GroupNorm on load, the head's 96 rows of the qkv 1x1 conv and softmax(q k^T) v run out of
+ * registers and LDS; the 3C-wide qkv tensor never reaches memory.  proj_out + residual remain a ccdm_conv2d (1x1, resid = x).
+ * Built for head width 32 and (T, C) in {64,256} x {96,128} and 128 x {128,256} — ccdm_norm_qkv_attention_supported(); every
+ * other geometry runs as ccdm_conv2d (GN + qkv) -> ccdm_attention.  CCDM_PREC_F16X3 arithmetic.
+ *   wqkv : qkv.weight [3C,C,1] with rows in LEGACY order (channel = head*96 + {q,k,v}*32 + d; the host permutes the rows of a
+ *          `use_new_attention_order` model), packed by ccdm_pack_conv_weight(…, Cout=3C, Cin=C, ksize=1, CCDM_PREC_F16X3); bqkv alike.
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct ccdm_attn_block_args {
+    const float* x;                                  /* dev [N,T,C] block input (NHWC, T = h*w) */
+    const double* stats; int32_t slices;             /* dev [N,slices,C,2] partial statistics of x */
+    const float* gamma; const float* beta; float eps;/* AttentionBlock.norm */
+    const void* wqkv; const float* bqkv;             /* packed qkv weights (see above), dev [3C] bias in legacy order */
+    float* out;                                      /* dev [N,T,C] attention output, channel = head*32 + d */
+    int32_t N, T, C, heads;
+} ccdm_attn_block_args;
+int ccdm_norm_qkv_attention_supported(int T, int C, int heads);
+int ccdm_norm_qkv_attention(const ccdm_attn_block_args* a, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Time conditioning for a list of steps (depends only on t, so computed once per run):
@@ -215,6 +240,8 @@ ccdm_engine* ccdm_engine_create(int32_t* step_counter /*dev scalar*/);
 void ccdm_engine_destroy(ccdm_engine* e);
 int ccdm_engine_add_conv(ccdm_engine* e, const ccdm_conv_args* a);          /* step_ptr is overridden with the engine's counter */
 int ccdm_engine_add_attention(ccdm_engine* e, const float* qkv, float* out, int N, int T, int C, int heads, int order);
+int ccdm_engine_add_norm_qkv_attention(ccdm_engine* e, const ccdm_attn_block_args* a);
+int ccdm_engine_add_stats_fold(ccdm_engine* e, const double* in, int N, int S_in, int C, int S_out, double* out);
 int ccdm_engine_set_epilogue(ccdm_engine* e, const ccdm_post_args* a);      /* run after the ops of each step */
 int ccdm_engine_num_ops(const ccdm_engine* e);
 /* per-run mutable fields of the epilogue (everything else is fixed at build time) */

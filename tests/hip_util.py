@@ -147,3 +147,23 @@ def posterior_sample(head_nhwk, xt_idx, a, c, mode, *, softmax=True, noise=None,
     hip.check(lib.ccdm_posterior_sample(C.byref(p), 0), "posterior_sample")
     sync()
     return dict(xt_next=xt_next.cpu(), xin=xin.cpu(), probs=probs.cpu(), onehot=onehot.cpu(), posterior=post.cpu())
+
+
+def norm_qkv_attention(x_nhwc, norm_w, norm_b, qkv_w, qkv_b, heads: int, new_order: bool):
+    """ccdm_norm_qkv_attention: GroupNorm + qkv + attention core in one launch.  x [N,h,w,C] cuda; parameters as numpy in the
+    reference's layout.  Returns the attention output [N,h,w,C] (channel = head*32 + d)."""
+    lib = hip.load()
+    N, h, w, Cc = x_nhwc.shape
+    st = gn_stats(x_nhwc, 1)
+    wq, bq = hip.pack_qkv_weights(qkv_w, qkv_b, heads, new_order)
+    dev = [torch.from_numpy(np.ascontiguousarray(v)).to(DEV) for v in (wq, bq, np.asarray(norm_w, np.float32), np.asarray(norm_b, np.float32))]
+    out = torch.full_like(x_nhwc, float("nan"))
+    a = hip.AttnBlockArgs()
+    a.x, a.stats, a.slices = x_nhwc.data_ptr(), st.data_ptr(), 1
+    a.gamma, a.beta, a.eps = dev[2].data_ptr(), dev[3].data_ptr(), 1e-5
+    a.wqkv, a.bqkv = dev[0].data_ptr(), dev[1].data_ptr()
+    a.out = out.data_ptr()
+    a.N, a.T, a.C, a.heads = N, h * w, Cc, heads
+    hip.check(lib.ccdm_norm_qkv_attention(C.byref(a), 0), "norm_qkv_attention")
+    sync()
+    return out

