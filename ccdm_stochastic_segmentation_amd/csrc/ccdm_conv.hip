@@ -372,7 +372,10 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
             return x * __builtin_amdgcn_rcpf(1.0f / PS + __builtin_amdgcn_exp2f(fmaf(x, -1.4426950408889634f, F16 ? -4.0f : 0.0f)));
         };
         static_assert(ACT_PRESCALE == 16.0f, "the exp2 bias above is log2(ACT_PRESCALE)");
-        auto put = [&](const f32x4 r, const bool ok, const int hp) {
+        // MASKED = false: the item is known to lie inside the image (core columns of an image whose width is a multiple of the
+        // tile, rows tested by the caller): no padding select at all.
+        auto put = [&](auto MASKED_, const f32x4 r, const bool ok, const int hp) {
+            constexpr bool MASKED = decltype(MASKED_)::value;
             float4 v = make_float4(r[0], r[1], r[2], r[3]);
             if (GN) { v.x = fmaf(v.x, t0.x, t0.y); v.y = fmaf(v.y, t1.x, t1.y); v.z = fmaf(v.z, t2.x, t2.y); v.w = fmaf(v.w, t3.x, t3.y); }
             v.x = act(v.x); v.y = act(v.y); v.z = act(v.z); v.w = act(v.w);
@@ -385,38 +388,60 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                 // becomes inf, lo = x - inf = -inf, and every output it reaches is NaN — the step epilogue raises the engine's
                 // sticky range flag on it and the host falls back to the exact-fp32 kernels (include/ccdm_hip.h).  The median
                 // below only zeroes padding: its bound is 0 there and infinite elsewhere (one select per item; lo = 0 - 0 follows).
-                const float lim = ok ? __builtin_inff() : 0.f;
-                v.x = __builtin_amdgcn_fmed3f(v.x, -lim, lim); v.y = __builtin_amdgcn_fmed3f(v.y, -lim, lim);
-                v.z = __builtin_amdgcn_fmed3f(v.z, -lim, lim); v.w = __builtin_amdgcn_fmed3f(v.w, -lim, lim);
-                f16x4 hi, lo;
-                hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
-                lo[0] = (_Float16)(v.x - (float)hi[0]); lo[1] = (_Float16)(v.y - (float)hi[1]);
-                lo[2] = (_Float16)(v.z - (float)hi[2]); lo[3] = (_Float16)(v.w - (float)hi[3]);
+                if (MASKED) {
+                    const float lim = ok ? __builtin_inff() : 0.f;
+                    v.x = __builtin_amdgcn_fmed3f(v.x, -lim, lim); v.y = __builtin_amdgcn_fmed3f(v.y, -lim, lim);
+                    v.z = __builtin_amdgcn_fmed3f(v.z, -lim, lim); v.w = __builtin_amdgcn_fmed3f(v.w, -lim, lim);
+                }
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                u32x2 hi, lo;
+                unsigned h0, l0, h1, l1;
+                split2_f16(v.x, v.y, h0, l0);
+                split2_f16(v.z, v.w, h1, l1);
+                hi[0] = h0; hi[1] = h1; lo[0] = l0; lo[1] = l1;
                 char* d = halo_b + hp * PIXB + 8 * tq;
-                *reinterpret_cast<f16x4*>(d) = hi;
-                *reinterpret_cast<f16x4*>(d + 2 * CK) = lo;
+                *reinterpret_cast<u32x2*>(d) = hi;
+                *reinterpret_cast<u32x2*>(d + 2 * CK) = lo;
             }
+        };
+        auto put_zero = [&](const int hp) {          // a halo row outside the image (wave-uniform): zeros, no arithmetic
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            u32x2 z;
+            z[0] = 0u; z[1] = 0u;
+            char* d = halo_b + hp * PIXB + 8 * tq;
+            *reinterpret_cast<u32x2*>(d) = z;
+            *reinterpret_cast<u32x2*>(d + 2 * CK) = z;
         };
         if constexpr (ROWS) {
             const int hp0 = rip * HWt + PAD + px;
+            if (ROW_UNIFORM && PREC != CCDM_PREC_F32 && k.core_unmasked) {
+                // the row test is wave-uniform (scalar branch); inside the image nothing is masked
 #pragma unroll
-            for (int i = 0; i < NCORE; ++i)
-                if ((i + 1) * RPP <= HHt || rip + i * RPP < HHt)
-                    put(reg[d][i], xok[d] & (((rowmask[d] >> i) & 1u) != 0u), hp0 + i * RPP * HWt);
+                for (int i = 0; i < NCORE; ++i)
+                    if ((i + 1) * RPP <= HHt || rip + i * RPP < HHt) {
+                        if (__builtin_amdgcn_readfirstlane((rowmask[d] >> i) & 1u)) put(std::false_type{}, reg[d][i], true, hp0 + i * RPP * HWt);
+                        else put_zero(hp0 + i * RPP * HWt);
+                    }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NCORE; ++i)
+                    if ((i + 1) * RPP <= HHt || rip + i * RPP < HHt)
+                        put(std::true_type{}, reg[d][i], xok[d] & (((rowmask[d] >> i) & 1u) != 0u), hp0 + i * RPP * HWt);
+            }
 #pragma unroll
             for (int j = 0; j < NEDGE; ++j) {
                 const unsigned e = t_ + j * NT;
                 if (e < (unsigned)EDGE_ITEMS) {
                     const unsigned side = (e / QPP) % ECOLS, row = e / (ECOLS * QPP);
                     const int hx = side < (unsigned)PAD ? (int)side : TW + (int)side;
-                    put(reg[d][NCORE + j], ((evalid[d] >> j) & 1u) != 0u, (int)row * HWt + hx);
+                    put(std::true_type{}, reg[d][NCORE + j], ((evalid[d] >> j) & 1u) != 0u, (int)row * HWt + hx);
                 }
             }
         } else {
 #pragma unroll
             for (int i = 0; i < NITEM; ++i) {
                 const unsigned item = t_ + i * NT;
-                if (item < (unsigned)(HP * QPP)) put(reg[d][i], ((valid[d] >> i) & 1u) != 0u, (int)(item / QPP));
+                if (item < (unsigned)(HP * QPP)) put(std::true_type{}, reg[d][i], ((valid[d] >> i) & 1u) != 0u, (int)(item / QPP));
             }
         }
         if (PREC != CCDM_PREC_F32) {
@@ -904,6 +929,8 @@ int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
 
     ConvK k;
     k.a = a;
+    k.timeline = nullptr;
+    k.core_unmasked = 0;
     const int prec = a.prec & 255;
     k.cin_pad = cin_pad_for(C, prec);
     k.cin_pad_skip = a.skip0 ? cin_pad_for(a.SC0 + a.SC1, prec) : 0;
@@ -928,6 +955,11 @@ int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
     if (a.out_stats) CCDM_REQUIRE(a.out_slices == k.slices, "conv: out_slices %d != %d", a.out_slices, k.slices);
     const int HP = ((g.TH - 1) * a.stride + a.ksize) * ((g.TW - 1) * a.stride + a.ksize);
     const int ck = chunk_ck(a, g);
+    {   // core halo items need no per-lane padding mask when every tile column and every channel quad exists (see ConvK)
+        const int SC = a.SC0 + a.SC1;
+        const bool chan_ok = a.C0 % ck == 0 && a.C1 % ck == 0 && (!a.skip0 || (a.SC0 % ck == 0 && a.SC1 % ck == 0 && SC > 0));
+        k.core_unmasked = (a.stride == 1 && Wc % g.TW == 0 && chan_ok) ? 1 : 0;
+    }
     CCDM_REQUIRE(a.C1 == 0 || a.C0 % ck == 0, "conv: first source has %d channels; a concatenated input must split at a multiple of the %d-channel chunk", a.C0, ck);
     CCDM_REQUIRE(a.SC1 == 0 || a.SC0 % ck == 0, "conv: first skip source has %d channels; a concatenated input must split at a multiple of the %d-channel chunk", a.SC0, ck);
     CCDM_REQUIRE((k.cin_pad + k.cin_pad_skip) / ck <= 64, "conv: %d input (+%d skip) channels make more than 64 chunks of %d (chunk descriptors live in the 64 lanes of a register)",
@@ -944,6 +976,12 @@ int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
     if ((a.prec >> 8) & 512) lds = 60 * 1024;      // diagnostics (tools/bench_conv.py): at most 2 blocks per CU
     if ((a.prec >> 8) & 1024) lds = 100 * 1024;    //                                   1 block per CU
     CCDM_REQUIRE(lds <= 160 * 1024, "conv: LDS %zu too large", lds);
+    if (conv_pc_eligible(k, g, NI)) {          // full-width 3x3 stages: producer/consumer form (ccdm_conv_pc.hip)
+        const int rc_pc = launch_conv_pc(k, s);
+        if (rc_pc) return rc_pc;
+        CCDM_CHECK_LAUNCH("conv(pc)");
+        return 0;
+    }
     dim3 grid(a.N * k.slices, k.ntiles / NI);
     const int rc = prec == CCDM_PREC_F32 ? launch_prec<CCDM_PREC_F32>(k, g, NI, ck, grid, lds, s)
                                            : launch_prec<CCDM_PREC_F16X3>(k, g, NI, ck, grid, lds, s);
@@ -961,6 +999,7 @@ extern "C" int ccdm_conv_slices(int Hout, int Wout, int stride, int ksize) {
 
 extern "C" int ccdm_debug_read_timeline(unsigned long long* host, int n) {
     if (!host || n <= 0 || n > 1024) return ccdm::fail("debug_read_timeline: bad args");
+    if (ccdm::conv_pc_timeline_read(host, n)) return 0;
     if (hipMemcpyFromSymbol(host, HIP_SYMBOL(ccdm::g_timeline), (size_t)n * 8, 0, hipMemcpyDeviceToHost) != hipSuccess)
         return ccdm::fail("debug_read_timeline: copy failed");
     return 0;

@@ -26,12 +26,31 @@ __device__ __forceinline__ void store16_uniform_base(char* base, unsigned voff, 
     if (NT) __builtin_nontemporal_store(v, reinterpret_cast<__attribute__((address_space(1))) f32x4*>(g + voff));
     else *reinterpret_cast<__attribute__((address_space(1))) f32x4*>(g + voff) = v;
 }
+// fp16 hi/lo split of two fp32 values: hi = RNE(x) packed, lo = RNE(x - hi) packed.  x - hi is one v_fma_mix_f32 (the fp16 half is
+// read straight out of the packed register and widened by the instruction: fma(hi, -1, x), exactly the subtraction's single rounding),
+// instead of an unpack (v_cvt_f32_f16) plus a subtract per element: 4 VALU instructions per pair instead of 7.
+__device__ __forceinline__ void split2_f16(const float a, const float b, unsigned& hi, unsigned& lo) {
+    float la, lb;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(la) : "v"(hi), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lb) : "v"(hi), "v"(b));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(la), "v"(lb));
+}
+
 struct ConvK {   // kernel-side copy of ccdm_conv_args (+ derived)
     ccdm_conv_args a;
     int cin_pad, ntiles, slices, tiles_x, tiles_y;
     int cin_pad_skip;        // padded channels of the fused 1x1 skip segment (0: none)
     const float* wscale;     // F16X3: [ntiles*32] powers of two undoing the per-output-channel weight pre-scale
+    int core_unmasked;       // every core column of every tile lies inside the image and every channel quad exists (W % TW == 0, C % CK == 0):
+                             // core halo items need no per-lane padding mask, only the wave-uniform row test
+    unsigned long long* timeline;   // diagnostics (CCDM_PC_TIMELINE=1): s_memtime stamps of one mid-grid block, else NULL
 };
+
+// producer/consumer form of the full-width 3x3 stages (ccdm_conv_pc.hip)
+bool conv_pc_eligible(const ConvK& k, const ConvGeo& g, int NI);
+int launch_conv_pc(const ConvK& k, hipStream_t s);
+bool conv_pc_timeline_read(unsigned long long* host, int n);
 
 // ---------------------------------------------------------------------------------------------------
 // GroupNorm affine for sample n:  ab[c] = (scale, shift) such that  y = scale*x + shift

@@ -1261,9 +1261,10 @@ def test_stats_fold_and_large_image_slices(U):
     U.sync()
     y = U.bchw(out).double()
     tot = folded.cpu().sum(1)
-    assert torch.allclose(tot[..., 0], y.sum(dim=(2, 3)), rtol=1e-9, atol=1e-6)
-    assert torch.allclose(tot[..., 1], (y ** 2).sum(dim=(2, 3)), rtol=1e-9, atol=1e-6)
-    assert torch.equal(folded.cpu().sum(1), st.cpu().reshape(2, 8, 3, 32, 2).sum(2).sum(1)) or True      # order differs: only the totals are pinned above
+    # (partials are accumulated per lane in fp32 before they are widened: the totals agree to fp32 accumulation accuracy)
+    assert torch.allclose(tot[..., 0], y.sum(dim=(2, 3)), rtol=1e-6, atol=2e-3)
+    assert torch.allclose(tot[..., 1], (y ** 2).sum(dim=(2, 3)), rtol=1e-6, atol=2e-3)
+    assert torch.allclose(folded.cpu().sum(1), st.cpu().sum(1), rtol=1e-13, atol=1e-9)              # folding only regroups the slices
     # and the reference conv itself
     ref = F.conv2d(x.double(), w.double(), None, padding=1).float()
     assert (U.bchw(out) - ref).abs().max() < 2e-5

@@ -109,9 +109,34 @@ def run_fused_skip(prec, c0, c1, cout, H, W):
     return b["ms"]
 
 
+def timeline_pc(prec, shape):
+    """Producer/consumer kernel (CCDM_PC_TIMELINE=1): stamps of loader wave 0 and matrix wave 0 of one mid-grid block."""
+    run(prec, shape, iters=1)
+    lib = hip.load()
+    buf = (C.c_ulonglong * 1024)()
+    hip.check(lib.ccdm_debug_read_timeline(buf, 1024))
+    names = {1: "start", 2: "prologue-issued", 3: "barA", 4: "commit0+issue", 5: "barB", 10: "commit", 11: "issueB+issue", 12: "rows", 14: "barrier", 15: "tail-rows",
+             20: "mfma", 21: "acc->epi", 22: "barrier"}
+    for role, off in (("loader", 0), ("matrix", 512)):
+        n = int(buf[off])
+        ev = [(int(buf[off + 1 + i]) >> 56, int(buf[off + 1 + i]) & ((1 << 56) - 1)) for i in range(n)]
+        if not ev:
+            print(role, "no stamps"); continue
+        prev = ev[0][1]
+        out = []
+        for slot, t in ev[1:]:
+            out.append(f"{names.get(slot, slot)}+{t - prev}")
+            prev = t
+        print(f"{role}: total {prev - ev[0][1]} cycles: " + " ".join(out[:90]))
+
+
 if __name__ == "__main__":
     precs = [hip.PREC_F16X3] if len(sys.argv) < 2 else [int(v) for v in sys.argv[1].split(",")]
     only = int(sys.argv[2]) if len(sys.argv) > 2 else None
+    if os.environ.get("CCDM_PC_TIMELINE"):
+        for i in [int(v) for v in os.environ.get("TIMELINE", "0").split(",")]:
+            print(SHAPES[i]); timeline_pc(precs[0], SHAPES[i])
+        sys.exit(0)
     if os.environ.get("TIMELINE"):
         for i in [int(v) for v in os.environ["TIMELINE"].split(",")]:
             print(SHAPES[i]); timeline(precs[0], SHAPES[i])

@@ -4,6 +4,7 @@ set -u
 TAG=${1:-q}
 KEXPR=${2:-}
 CONFIGS=${3:-c2}
+AB_ENV=${4:-}          # e.g. "CCDM_NO_PC=1": a second bench pass of every config with these variables set (same box A/B)
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 if [ -n "$KEXPR" ]; then
@@ -12,6 +13,11 @@ if [ -n "$KEXPR" ]; then
 fi
 for c in $CONFIGS; do
   extra="--steps 2 --warmup 1 --no-cpu-baseline"
+  if [ -n "$AB_ENV" ]; then
+    env $AB_ENV timeout 900 python bench.py --config $c $extra --no-secondary > gpurun_out/bench_${c}_${TAG}_B.json 2> gpurun_out/bench_${c}_${TAG}_B.err
+    echo "== $c with $AB_ENV"; python -c "
+import json; d=json.load(open('gpurun_out/bench_${c}_${TAG}_B.json')); print({k: d[k] for k in ('value','ms_per_denoise_step')}, 'roofline', (d.get('roofline') or {}).get('avg_launch_ms'))" || tail -5 gpurun_out/bench_${c}_${TAG}_B.err
+  fi
   timeout 900 python bench.py --config $c $extra --per-op gpurun_out/per_op_${c}_$TAG.json > gpurun_out/bench_${c}_$TAG.json 2> gpurun_out/bench_${c}_$TAG.err
   echo "== $c"; python - "$c" "$TAG" <<'PY'
 import json, sys
