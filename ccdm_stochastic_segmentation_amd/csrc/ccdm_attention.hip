@@ -13,25 +13,52 @@
 // Precision: every product is the 3-term fp16 hi/lo split (lo*hi + hi*lo + hi*hi, fp32 accumulate, ~2^-22) used by
 // the convs; P in [0,1] needs no scaling.  exp is v_exp_f32.
 #include "ccdm_common.h"
+#include "ccdm_conv_common.h"
 
 namespace ccdm {
 
 static constexpr int KT = 64;              // keys per tile
 template <int D> struct KRow { static constexpr int B = 4 * D + 16; };   // bytes per K-tile row: D hi | D lo halfs | 16 pad (36 / 68 dwords: conflict-free b128)
-static constexpr int VROW = 2 * KT * 2 + 8;  // bytes per V^T row: 64 hi | 64 lo halfs | 8 pad (66 dwords... 8-B aligned, b64 reads)
+// V tile in LDS: row-major by key, in planes of 16 d-columns: [plane = d / 16][key 0..63][16 halfs = 32 B], + 128 B between planes so
+// that the two planes a 32-lane read group touches sit on opposite halves of the 64 banks.  The PV product needs V^T fragments
+// (row = d, 8 consecutive keys per lane): gfx950's ds_read_b64_tr_b16 returns exactly that from the row-major image — within each
+// group of 16 lanes, lane l receives column l of the [4 keys][16 d] block whose rows lanes 4j..4j+3 point at (measured:
+// tools/ubench/tr_b16_probe.hip) — so V is staged with 8-byte writes like K instead of being transposed with 2-byte writes.
+static constexpr int VPLANE = KT * 32 + 128;
 
-__device__ __forceinline__ void split4(const float4 v, f16x4& hi, f16x4& lo) {
-    hi[0] = (_Float16)v.x; hi[1] = (_Float16)v.y; hi[2] = (_Float16)v.z; hi[3] = (_Float16)v.w;
-    lo[0] = (_Float16)(v.x - (float)hi[0]); lo[1] = (_Float16)(v.y - (float)hi[1]);
-    lo[2] = (_Float16)(v.z - (float)hi[2]); lo[3] = (_Float16)(v.w - (float)hi[3]);
+#ifndef CCDM_ATTN_STAGE_FLOAT4
+#define CCDM_ATTN_STAGE_FLOAT4 0          // 1: stage K/V through HIP float4 structs instead of native vectors (tools/ubench/attn_float4_repro.sh)
+#endif
+#if CCDM_ATTN_STAGE_FLOAT4
+typedef float4 stage_t;
+__device__ __forceinline__ float sget(const stage_t& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w)); }
+#else
+typedef f32x4 stage_t;
+__device__ __forceinline__ float sget(const stage_t& v, int i) { return v[i]; }
+#endif
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// fp16 hi/lo split of 8 floats into MFMA operand fragments (split2_f16: ccdm_conv_common.h)
+__device__ __forceinline__ void split8_frag(const float* v, f16x8& hi, f16x8& lo) {
+    u32x4 h, l;
+    unsigned a, b;
+    split2_f16(v[0], v[1], a, b); h[0] = a; l[0] = b;
+    split2_f16(v[2], v[3], a, b); h[1] = a; l[1] = b;
+    split2_f16(v[4], v[5], a, b); h[2] = a; l[2] = b;
+    split2_f16(v[6], v[7], a, b); h[3] = a; l[3] = b;
+    hi = __builtin_bit_cast(f16x8, h);
+    lo = __builtin_bit_cast(f16x8, l);
 }
 
 template <int WAVES, int D>
 __global__ __launch_bounds__(WAVES * 64) void k_attention_mfma(const float* __restrict__ qkv, float* __restrict__ out,
                                                               int T, int Ta, int C, int order) {
     constexpr int NT = WAVES * 64, KROW = KRow<D>::B, DS = D / 16 /* 16-wide k-steps over d */, DM = D / 32 /* 32-row tiles of d */;
+    constexpr int NPL = D / 16, VLO = NPL * VPLANE;                // V planes; byte offset of the lo image
     __shared__ __attribute__((aligned(16))) char kt[KT * KROW];
-    __shared__ __attribute__((aligned(16))) char vt[D * VROW];
+    __shared__ __attribute__((aligned(16))) char vt[2 * NPL * VPLANE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = blockIdx.y, n = blockIdx.z;
     const int q0 = (blockIdx.x * WAVES + wave) * 32;
@@ -40,6 +67,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_attention_mfma(const float* __re
     if (order == 0) { qoff = h * 3 * D; koff = qoff + D; voff = qoff + 2 * D; }
     else { qoff = h * D; koff = C + h * D; voff = 2 * C + h * D; }
     const float scale = (float)(1.0 / sqrt(sqrt((double)D)));
+    // scores are kept in units of log2(e): softmax(s) = 2^(s' - max s') / sum with s' = s * log2(e), so every exponential is one
+    // v_exp_f32 with no multiply in front of it; the factor rides in the (already scaled) query
+    const float qscale = scale * 1.4426950408889634f;
     const float* base = qkv + (size_t)n * Ta * C3;
     const int qi = lane & 31, half = lane >> 5;
 
@@ -50,13 +80,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_attention_mfma(const float* __re
 #pragma unroll
         for (int s = 0; s < DS; ++s) {
             const float* p = base + (size_t)tq * C3 + qoff + 16 * s + 8 * half;
-            float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
-            a.x *= scale; a.y *= scale; a.z *= scale; a.w *= scale;
-            b.x *= scale; b.y *= scale; b.z *= scale; b.w *= scale;
-            f16x4 h0, l0, h1, l1;
-            split4(a, h0, l0); split4(b, h1, l1);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { qh[s][j] = h0[j]; qh[s][4 + j] = h1[j]; ql[s][j] = l0[j]; ql[s][4 + j] = l1[j]; }
+            const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+            const float v[8] = {a.x * qscale, a.y * qscale, a.z * qscale, a.w * qscale, b.x * qscale, b.y * qscale, b.z * qscale, b.w * qscale};
+            split8_frag(v, qh[s], ql[s]);
         }
     }
     f32x16 o[DM];
@@ -71,39 +97,41 @@ __global__ __launch_bounds__(WAVES * 64) void k_attention_mfma(const float* __re
     // runs under the matrix work instead of in front of the next staging pass.
     constexpr int NSTG = KT * (D / 4) / NT;
     static_assert(KT * (D / 4) % NT == 0, "staging items divide evenly over the block");
-    f32x4 pk[NSTG], pv[NSTG];
+    stage_t pk[NSTG], pv[NSTG];
     auto request = [&](const int j0) {
 #pragma unroll
         for (int u = 0; u < NSTG; ++u) {
             const int item = tid + u * NT;
             const int key = min(j0 + item / (D / 4), T - 1), c4 = item % (D / 4);
             const float* p = base + (size_t)key * C3;
-            pk[u] = *reinterpret_cast<const f32x4*>(p + koff + 4 * c4);
-            pv[u] = *reinterpret_cast<const f32x4*>(p + voff + 4 * c4);
+            pk[u] = *reinterpret_cast<const stage_t*>(p + koff + 4 * c4);
+            pv[u] = *reinterpret_cast<const stage_t*>(p + voff + 4 * c4);
         }
     };
+    // per-lane part of the V^T fragment address (ds_read_b64_tr_b16): group-local lane gl = lane & 15 points at row (gl >> 2) of the
+    // group's [4 keys][16 d] block, 4 halfs from column 4*(gl & 3); the group's d-plane is (lane >> 4) & 1, its key offset 4*half
+    const unsigned vlane = (unsigned)(size_t)vt + ((lane >> 4) & 1) * VPLANE + (4 * half + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
     request(0);
     for (int j0 = 0; j0 < T; j0 += KT) {
         __syncthreads();
-        // ---- stage K (row-major, scaled) and V (transposed) tiles as fp16 hi/lo ----
+        // ---- stage K (scaled) and V row-major as fp16 hi/lo ----
 #pragma unroll
         for (int u = 0; u < NSTG; ++u) {
             const int item = tid + u * NT;
             const int key = item / (D / 4), c4 = item % (D / 4);
             const bool in = j0 + key < T;
-            float4 kv = make_float4(in ? pk[u][0] : 0.f, in ? pk[u][1] : 0.f, in ? pk[u][2] : 0.f, in ? pk[u][3] : 0.f);
-            const float4 vv = make_float4(in ? pv[u][0] : 0.f, in ? pv[u][1] : 0.f, in ? pv[u][2] : 0.f, in ? pv[u][3] : 0.f);
-            kv.x *= scale; kv.y *= scale; kv.z *= scale; kv.w *= scale;
-            f16x4 hi, lo;
-            split4(kv, hi, lo);
-            *reinterpret_cast<f16x4*>(kt + key * KROW + 8 * c4) = hi;
-            *reinterpret_cast<f16x4*>(kt + key * KROW + 2 * D + 8 * c4) = lo;
-            split4(vv, hi, lo);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                *reinterpret_cast<_Float16*>(vt + (4 * c4 + e) * VROW + 2 * key) = hi[e];
-                *reinterpret_cast<_Float16*>(vt + (4 * c4 + e) * VROW + 2 * KT + 2 * key) = lo[e];
-            }
+            const float ks = in ? scale : 0.f, vs = in ? 1.f : 0.f;        // rows beyond T are staged as zeros
+            u32x2 hi, lo;
+            unsigned a, b;
+            split2_f16(sget(pk[u], 0) * ks, sget(pk[u], 1) * ks, a, b); hi[0] = a; lo[0] = b;
+            split2_f16(sget(pk[u], 2) * ks, sget(pk[u], 3) * ks, a, b); hi[1] = a; lo[1] = b;
+            *reinterpret_cast<u32x2*>(kt + key * KROW + 8 * c4) = hi;
+            *reinterpret_cast<u32x2*>(kt + key * KROW + 2 * D + 8 * c4) = lo;
+            split2_f16(sget(pv[u], 0) * vs, sget(pv[u], 1) * vs, a, b); hi[0] = a; lo[0] = b;
+            split2_f16(sget(pv[u], 2) * vs, sget(pv[u], 3) * vs, a, b); hi[1] = a; lo[1] = b;
+            char* vd = vt + (c4 >> 2) * VPLANE + key * 32 + (c4 & 3) * 8;
+            *reinterpret_cast<u32x2*>(vd) = hi;
+            *reinterpret_cast<u32x2*>(vd + VLO) = lo;
         }
         __syncthreads();
         if (j0 + KT < T) request(j0 + KT);
@@ -125,47 +153,58 @@ __global__ __launch_bounds__(WAVES * 64) void k_attention_mfma(const float* __re
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], acc, 0, 0, 0);
                 }
-                // acc[r] = score(query = lane&31, key = 32*st + (r&3) + 8*(r>>2) + 4*half); mask keys beyond T
+                // acc[r] = score(query = lane&31, key = 32*st + (r&3) + 8*(r>>2) + 4*half); only the sample's last tile can hold keys beyond T
+                if (j0 + KT > T) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = j0 + 32 * st + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    acc[r] = key < T ? acc[r] : -INFINITY;
-                    mx = fmaxf(mx, acc[r]);
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = j0 + 32 * st + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        acc[r] = key < T ? acc[r] : -INFINITY;
+                    }
                 }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc[r]);
                 sc[st] = acc;
             }
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float corr = __expf(m - mx);            // first tile: exp(-inf) = 0
-        m = mx;
-        l *= corr;
+        if (__builtin_amdgcn_ballot_w64(mx > m) != 0ull) {     // some query's running maximum grew: rescale (else the factor is exactly 1)
+            const float corr = __builtin_amdgcn_exp2f(m - mx);     // first tile: 2^(-inf) = 0
+            m = mx;
+            l *= corr;
 #pragma unroll
-        for (int mt = 0; mt < DM; ++mt)
+            for (int mt = 0; mt < DM; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[mt][r] *= corr;
+                for (int r = 0; r < 16; ++r) o[mt][r] *= corr;
+        }
 #pragma unroll
         for (int st = 0; st < 2; ++st) {
             if (st < nsub) {
                 float p[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { p[r] = __expf(sc[st][r] - mx); l += p[r]; }
+                for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(sc[st][r] - mx); l += p[r]; }
                 // O^T += V^T * P^T.  k-step s covers this lane's registers r = 8s..8s+7, i.e. keys
-                // 32*st + 16*s + {0..3, 8..11} + 4*half — the same keys are read from V^T for the A operand.
+                // 32*st + 16*s + {0..3, 8..11} + 4*half — the same keys are read (transposed) from the V image for the A operand.
+                // (Issuing a whole sub-tile's fragment reads ahead of the exponentials and waiting behind them was tried: +1 % at
+                //  T = 8192 and a wrong result in the head-width-64 instantiation — a register the compiler moved between the two
+                //  asm statements — so each group of reads keeps its wait in the same statement.)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     f16x8 ph, pl;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float pv = p[8 * s + j];
-                        ph[j] = (_Float16)pv;
-                        pl[j] = (_Float16)(pv - (float)ph[j]);
-                    }
+                    split8_frag(p + 8 * s, ph, pl);
 #pragma unroll
                     for (int mt = 0; mt < DM; ++mt) {
-                        const char* vp = vt + (32 * mt + qi) * VROW + 2 * (32 * st + 16 * s + 4 * half);     // row d = 32*mt + lane&31
+                        // lane (d = 32*mt + lane&31, half): hi keys +0..3, +8..11, then the same of the lo image
+                        f16x4 vh0, vh1, vl0, vl1;
+                        const unsigned va = vlane + (32 * st + 16 * s) * 32 + 2 * mt * VPLANE;
+                        asm volatile("ds_read_b64_tr_b16 %0, %4\n\t"
+                                     "ds_read_b64_tr_b16 %1, %4 offset:256\n\t"
+                                     "ds_read_b64_tr_b16 %2, %4 offset:%5\n\t"
+                                     "ds_read_b64_tr_b16 %3, %4 offset:%6\n\t"
+                                     "s_waitcnt lgkmcnt(0)"
+                                     : "=&v"(vh0), "=&v"(vh1), "=&v"(vl0), "=&v"(vl1)
+                                     : "v"(va), "i"(VLO), "i"(VLO + 256)
+                                     : "memory");
                         f16x8 vh, vl;
-                        const f16x4 vh0 = *reinterpret_cast<const f16x4*>(vp), vh1 = *reinterpret_cast<const f16x4*>(vp + 16);
-                        const f16x4 vl0 = *reinterpret_cast<const f16x4*>(vp + 2 * KT), vl1 = *reinterpret_cast<const f16x4*>(vp + 2 * KT + 16);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) { vh[j] = vh0[j]; vh[4 + j] = vh1[j]; vl[j] = vl0[j]; vl[4 + j] = vl1[j]; }
                         o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, o[mt], 0, 0, 0);

@@ -16,7 +16,10 @@ ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("CCDM_LIB") or os.path.join(_HERE, "libccdm_hip.so")      # CCDM_LIB: A/B two builds on one GPU box
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ["ccdm_conv.hip", "ccdm_conv_pc.hip", "ccdm_misc.hip", "ccdm_attention.hip", "ccdm_attn_block.hip", "ccdm_sampler.hip", "ccdm_metrics.hip", "ccdm_engine.hip"]
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+# -amdgpu-mfma-vgpr-form: MFMA accumulators stay in the (unified) VGPR file.  The default heuristic parks them in AccVGPRs and pays a
+# v_accvgpr_read/_write for every vector op that touches a score or an output accumulator: 240 extra instructions per key tile in
+# the attention kernels (2066 in ccdm_attention.hip, 576 in ccdm_attn_block.hip; the conv kernels have none either way).
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fPIC", "-shared"]
 
 ACT_NONE, ACT_SILU = 0, 1
 PREC_F32, PREC_F16X3 = 0, 1

@@ -1268,3 +1268,37 @@ def test_stats_fold_and_large_image_slices(U):
     # and the reference conv itself
     ref = F.conv2d(x.double(), w.double(), None, padding=1).float()
     assert (U.bchw(out) - ref).abs().max() < 2e-5
+
+
+# ------------------------------------------------------------------------------------------ attention stress: MFMA vs VALU kernel
+def test_attention_stress_mfma_vs_valu(U, parity_log):
+    """1000 launches of the matrix-core attention kernel over (T, allocated rows, heads, head width, order) — padded rows, ragged last
+    tiles, the last (sample, head) included: every launch must equal the first one bit-for-bit (no race, no dependence on what a
+    previous launch left in LDS or registers) and the VALU kernel (an independent implementation, test hook `order | 256`) within
+    1e-5.  Guards the staging path that once returned wrong rows in the last (sample, head) when its register arrays were HIP
+    float4 structs (tools/ubench/attn_float4_repro.sh rebuilds that variant and runs this test against it)."""
+    import os
+    lib = hip.load()
+    cases = [(3, 256, 256, 96, 3, 0), (5, 64, 64, 128, 4, 1), (2, 2048, 2048, 64, 2, 0), (1, 8192, 8192, 128, 4, 0),
+             (3, 2049, 2064, 384, 6, 1), (2, 197, 208, 384, 6, 1), (4, 512, 512, 128, 4, 0), (2, 33, 48, 128, 2, 1)]
+    iters = int(os.environ.get("CCDM_STRESS_ITERS", "1000")) // len(cases)
+    worst = 0.0
+    for (N, T, Ta, C, heads, order) in cases:
+        g = torch.Generator(device="cpu").manual_seed(T + C)
+        qkv = (torch.randn((N, Ta, 3 * C), generator=g) * 1.2).to(U.DEV)
+        out = torch.full((N, Ta, C), float("nan"), device=U.DEV)
+        ref = torch.full((N, Ta, C), float("nan"), device=U.DEV)
+        hip.check(lib.ccdm_attention_ex(qkv.data_ptr(), ref.data_ptr(), N, T, Ta, C, heads, order | 256, 0), "attention(valu)")
+        first = None
+        for it in range(iters):
+            out.fill_(float("nan"))
+            hip.check(lib.ccdm_attention_ex(qkv.data_ptr(), out.data_ptr(), N, T, Ta, C, heads, order, 0), "attention(mfma)")
+            got = out[:, :T].clone()
+            if first is None:
+                first = got
+                d = (first - ref[:, :T]).abs().max().item()
+                worst = max(worst, d)
+                assert torch.isfinite(first).all() and d < 1e-5, (N, T, Ta, C, heads, order, d)
+            else:
+                assert torch.equal(got, first), f"launch {it} of {(N, T, Ta, C, heads, order)} differs from the first"
+    parity_log("attention_stress_mfma_vs_valu", launches=iters * len(cases), max_abs_diff_vs_valu=worst)
