@@ -277,7 +277,11 @@ class DenoisingModel(nn.Module):
         self.sample_offset = 0          # global index of sample 0 when the batch is sharded over ranks
         self.noise_slice: Optional[Tuple[int, int]] = None   # (global_batch, first_sample) for torch_cpu sharding
         self.use_graph = False
-        self.substreams = 1             # > 1: the batch is sampled as that many contiguous sub-batches on concurrent HIP streams
+        # the batch is sampled as this many contiguous sub-batches on concurrent HIP streams (bit-identical samples).  2 is worth
+        # +5 % at N = 64 (the low-resolution kernels of one half run beside the full-width kernels of the other; bench.py reports it
+        # as `substreams2`); the default stays 1 so that a kernel's measured duration describes that kernel.  0 = automatic: two
+        # from 32 samples up, one below.
+        self.substreams = 1
         self.prec = hip.PREC_F16X3
         # what to do when a PREC_F16X3 run reports a range overflow (hip.CcdmRangeError): "f32" = repeat the call with the
         # exact-fp32 kernels (same seeds, so the samples are the ones an all-fp32 run would have drawn) and log a warning;
@@ -405,7 +409,8 @@ class DenoisingModel(nn.Module):
         # fill a fraction of the GPU; two sub-batches half a step apart fill each other's gaps.  Nothing a sample sees
         # depends on the split (statistics are per sample, slices are a function of the spatial size only, noise is keyed
         # by the global sample index or sliced from the full-batch host draw): the results are bit-identical.
-        nsub = max(1, min(int(self.substreams), N))
+        nsub = int(self.substreams) if int(self.substreams) > 0 else (2 if N >= 32 else 1)
+        nsub = max(1, min(nsub, N))
         bounds = [(N * j) // nsub for j in range(nsub + 1)]
         parts = []
         for j in range(nsub):
