@@ -487,8 +487,8 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
             advance(pf_ch, pf_ty, pf_tx);
         }
     }
-    // GroupNorm's (scale, shift) table for this sample — after the first halo request is on its way: the statistics loads
-    // and the fp64 finalisation (~1.5 us) then run under that request's round trip instead of in front of it
+    // GroupNorm's (scale, shift) table for this sample — after the first halo request is on its way; the statistics partials of a
+    // channel are fetched 16 at a time (one L2 round trip, not one per partial), the fp64 finalisation follows
     if (has_gn) compute_gn_affine(a, n, emb_row, ab);
     // one iteration = one (tile, chunk); D_ = the register set it consumes (static: the loop below is unrolled by DEPTH)
     auto iterate = [&](auto D_) {

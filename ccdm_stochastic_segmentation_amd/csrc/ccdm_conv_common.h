@@ -54,38 +54,81 @@ bool conv_pc_timeline_read(unsigned long long* host, int n);
 
 // ---------------------------------------------------------------------------------------------------
 // GroupNorm affine for sample n:  ab[c] = (scale, shift) such that  y = scale*x + shift
+//
+// Two halves so that a kernel can put its first HBM requests between them:
+//   gn_group_sums  — the (sum, sum^2) of channel c's group: every (channel of the group, slice) partial, added in ascending
+//                    (channel, slice) order.  The partials are fetched 16 at a time with independent loads — one L2 round trip per 16
+//                    instead of one per partial (12 dependent round trips = 2.6 us per block at the 128x128 stage before).
+//   gn_finalize    — mean / rstd in fp64, gamma / beta (and FiLM) folded into one (scale, shift) pair.
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void compute_gn_affine(const ccdm_conv_args& a, int n, int emb_row, float2* ab) {
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void gn_group_sums(const ccdm_conv_args& a, int n, int c, double& sum, double& sq) {
+    const int C = a.C0 + a.C1;
+    const int cpg = C / 32;
+    const int c_lo = (c / cpg) * cpg, c_hi = c_lo + cpg;
+    sum = 0.0; sq = 0.0;
+    int cc = c_lo, s = 0;
+    while (cc < c_hi) {
+        f64x2 v[16];
+        bool ok[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            ok[u] = cc < c_hi;
+            const int ccl = ok[u] ? cc : c_hi - 1;                       // clamped: the load stays unconditional
+            const bool second = ccl >= a.C0;
+            const double* st = second ? a.stats1 : a.stats0;
+            const int ci = second ? ccl - a.C0 : ccl, Cs = second ? a.C1 : a.C0, S = second ? a.slices1 : a.slices0;
+            const int sl = ok[u] ? s : 0;
+            v[u] = *reinterpret_cast<const f64x2*>(st + (((size_t)n * S + sl) * Cs + ci) * 2);
+            if (++s >= S) { s = 0; ++cc; }
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {                                   // fixed order: ascending (channel, slice)
+            sum += ok[u] ? v[u][0] : 0.0;
+            sq += ok[u] ? v[u][1] : 0.0;
+        }
+    }
+}
+
+// per-channel parameters of the affine, fetched ahead of the arithmetic (gn_params) so that a kernel can issue every small load
+// before its first HBM request and do the fp64 finalisation (gn_finalize: registers only) while that request is in flight
+struct GnParams { float gamma, beta, film_scale, film_shift; };
+__device__ __forceinline__ GnParams gn_params(const ccdm_conv_args& a, int emb_row, int c) {
+    GnParams p;
+    p.gamma = a.gamma[c]; p.beta = a.beta[c]; p.film_scale = 0.f; p.film_shift = 0.f;
+    if (a.film) {
+        const float* row = a.emb_table + (size_t)emb_row * a.emb_stride + a.film_off;
+        p.film_scale = row[c]; p.film_shift = row[a.C0 + a.C1 + c];
+    }
+    return p;
+}
+__device__ __forceinline__ float2 gn_finalize(const ccdm_conv_args& a, const GnParams& p, double sum, double sq) {
     const int C = a.C0 + a.C1;
     const int cpg = C / 32;
     const double cnt = (double)cpg * (double)a.Hin * (double)a.Win;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const int c_lo = (c / cpg) * cpg;
-        double sum = 0.0, sq = 0.0;
-        for (int cc = c_lo; cc < c_lo + cpg; ++cc) {
-            const double* st; int ci, Cs, S;
-            if (cc < a.C0) { st = a.stats0; ci = cc; Cs = a.C0; S = a.slices0; }
-            else { st = a.stats1; ci = cc - a.C0; Cs = a.C1; S = a.slices1; }
-            const double* p = st + ((size_t)n * S * Cs + ci) * 2;
-            for (int s = 0; s < S; ++s) {
-                sum += p[(size_t)s * Cs * 2];
-                sq += p[(size_t)s * Cs * 2 + 1];
-            }
-        }
-        const double mean = sum / cnt;
-        double var = sq / cnt - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
-        const float meanf = (float)mean;
-        float sc = rstd * a.gamma[c];
-        float sh = a.beta[c] - sc * meanf;
-        if (a.film) {   // h = GN(h) * (1 + scale) + shift          unet.py:254-258
-            const float* row = a.emb_table + (size_t)emb_row * a.emb_stride + a.film_off;
-            const float one_plus = 1.0f + row[c];
-            sc = sc * one_plus;
-            sh = sh * one_plus + row[C + c];
-        }
-        ab[c] = make_float2(sc, sh);
+    const double mean = sum / cnt;
+    double var = sq / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+    const float meanf = (float)mean;
+    float sc = rstd * p.gamma;
+    float sh = p.beta - sc * meanf;
+    if (a.film) {   // h = GN(h) * (1 + scale) + shift          unet.py:254-258
+        const float one_plus = 1.0f + p.film_scale;
+        sc = sc * one_plus;
+        sh = sh * one_plus + p.film_shift;
+    }
+    return make_float2(sc, sh);
+}
+
+__device__ __forceinline__ void compute_gn_affine(const ccdm_conv_args& a, int n, int emb_row, float2* ab, int c_first = 0) {
+    const int C = a.C0 + a.C1;
+    for (int c = c_first + threadIdx.x; c < C; c += blockDim.x) {
+        double sum, sq;
+        const GnParams p = gn_params(a, emb_row, c);
+        gn_group_sums(a, n, c, sum, sq);
+        ab[c] = gn_finalize(a, p, sum, sq);
     }
 }
 
