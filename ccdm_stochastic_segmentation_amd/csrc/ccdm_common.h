@@ -34,8 +34,11 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 struct ConvGeo {
     int TH, TW, waves, MI;   // output tile, waves per block, 32-pixel sub-tiles per wave
 };
-static inline ConvGeo conv_geo(int Hout, int Wout, int stride) {
+// up2: the sub-pixel upsample form tiles the low-resolution INPUT space; its blocks carry four phases of accumulators, so it
+// never takes the two-sub-tile 8x32 geometry
+static inline ConvGeo conv_geo(int Hout, int Wout, int stride, bool up2 = false) {
     (void)Hout;
+    if (up2) return Wout >= 16 ? ConvGeo{8, 16, 4, 1} : ConvGeo{8, 8, 2, 1};
     if (stride == 2) return Wout >= 16 ? ConvGeo{8, 16, 4, 1} : ConvGeo{8, 8, 2, 1};     // (8x16: 4-wave blocks, 57 -> 49 us at 128x128 -> 64x64)
     if (Wout >= 32) return {8, 32, 4, 2};
     if (Wout >= 16) return {8, 16, 4, 1};

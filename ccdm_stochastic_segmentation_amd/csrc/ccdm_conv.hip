@@ -77,10 +77,21 @@ constexpr int min_waves(int mi, int ni, int prec, int ckt, int threads) {
 // (group r multiplies only taps (r, *)); their partial accumulators meet in the epilogue's LDS buffer.  A few-pixel
 // stage has too few tiles to fill the chip with pixel parallelism alone — this triples the waves per tile and cuts
 // the per-wave MFMA chain to a third.
-template <int PREC, int CKT, int KS, int STRIDE, int TH, int TW, int WAVES, int MI, int NI, int KSP = 1>
+//
+// UP2 (nearest x2 upsample + 3x3 conv in sub-pixel form, include/ccdm_hip.h `up = 2`): tiles, halo and staging live in the
+// LOW-resolution input space exactly as for a plain 3x3 conv; an output-channel tile of the launch is a (real channel tile,
+// phase) pair (n-tile = 4 * tile + phase), phase (dy, dx) multiplies the 2x2 taps at halo offset (dy + a, dx + b) with its own
+// (pre-summed) weights and the epilogue writes pixel (2y + dy, 2x + dx).  4 taps instead of 9 per output pixel.
+// NI = 4: one block computes all four phases of a channel tile from ONE staged halo (a quarter of the staging work per output
+// pixel): the tap walk visits the 9 halo positions once and feeds each A fragment to the 1, 2 or 4 phases whose window contains
+// it; the phases' statistics fold into the block's one partial.  NI = 1 (8x8 inputs, where blocks are scarce): one phase per
+// block, statistics slot = slice * 4 + phase.
+template <int PREC, int CKT, int KS, int STRIDE, int TH, int TW, int WAVES, int MI, int NI, int KSP = 1, bool UP2 = false>
 __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVES * KSP * 64)) void k_conv(const ConvK k) {
     constexpr int NT = WAVES * KSP * 64;
     static_assert(KSP == 1 || KSP == KS, "tap split is by kernel row");
+    static_assert(!UP2 || (KS == 3 && STRIDE == 1 && KSP == 1 && (NI == 1 || NI == 4) && PREC != CCDM_PREC_F32), "sub-pixel form: 3x3, stride 1, F16X3, one phase or all four");
+    constexpr int NTAP = UP2 ? 4 : KS * KS;
     constexpr int CK = Lds<PREC, CKT>::CK, PIXB = Lds<PREC, CKT>::PIXB;
     constexpr int KST = CK / 16;                                  // F16X3: 16-channel MFMA k-steps per chunk
     constexpr int PAD = KS / 2;
@@ -107,7 +118,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
     // F16X3: the chunk's B fragments, [tap][k-step] slabs of G = [ni][hi|lo][64 lanes] x 16 B, staged through registers
     // like the halo.  A pass covers MB whole slabs (or 1/DB of one); the slab index is wave-uniform.
     constexpr int G = NI * 128;
-    constexpr int NB4 = PREC == CCDM_PREC_F32 ? 0 : KS * KS * KST * G;
+    constexpr int NB4 = PREC == CCDM_PREC_F32 ? 0 : NTAP * KST * G;
     constexpr int NITEM_B = (NB4 + NT - 1) / NT;
     constexpr bool B_MULTI = NT % G == 0;
     static_assert(PREC == CCDM_PREC_F32 || B_MULTI || G % NT == 0, "B slabs must tile the block");
@@ -130,7 +141,10 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
     if ((gridDim.x & 7) == 0) bid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     const int n = bid / k.slices, slice = bid % k.slices;
     const int nt0 = blockIdx.y * NI;
-    const int Hc = a.up ? a.Hin * 2 : a.Hin, Wc = a.up ? a.Win * 2 : a.Win;    // conv-input space
+    // sub-pixel form: n-tile = 4 * (real channel tile) + phase
+    auto tile_of = [&](const int ni) { return UP2 ? (nt0 + ni) >> 2 : nt0 + ni; };      // real 32-channel tile of n-tile ni
+    auto phase_of = [&](const int ni) { return UP2 ? (nt0 + ni) & 3 : 0; };
+    const int Hc = (a.up && !UP2) ? a.Hin * 2 : a.Hin, Wc = (a.up && !UP2) ? a.Win * 2 : a.Win;    // conv-input space (= tile space)
     const int step = a.step_ptr ? *a.step_ptr : 0;
     const int emb_row = (a.emb_row_of_sample ? a.emb_row_of_sample[n] : 0) + step;
     const bool has_gn = a.stats0 != nullptr;
@@ -150,6 +164,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
         const int p = (wave * MI + mi) * 32 + (lane & 31);
         const int hpix = (p / TW) * STRIDE * HWt + (p % TW) * STRIDE;
         base[mi] = PREC == CCDM_PREC_F32 ? hpix * 33 + (lane >> 5) : hpix * PIXB + (lane >> 5) * 16;   // floats | bytes
+        if (UP2 && NI == 1) base[mi] += ((phase_of(0) >> 1) * HWt + (phase_of(0) & 1)) * PIXB;   // this phase's 2x2 window starts at halo offset (dy, dx)
     }
     // output statistics: slow epilogue -> lane = channel (index 0 used); fast epilogue -> lane = (pixel, channel quad)
     // (fp32 per lane: <= a few hundred values each; widened to fp64 before lanes, waves and slices are combined)
@@ -165,14 +180,14 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
     float epi_add[NI], epi_wsc[NI];
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
-        const int co = (nt0 + ni) * 32 + (lane & 31);
+        const int co = tile_of(ni) * 32 + (lane & 31);              // real output channel
         epi_add[ni] = 0.f; epi_wsc[ni] = 1.0f;
         if (co < a.Cout) {
             if (krow == 0) {                        // bias (+emb) enters once, through row group 0's partial
                 epi_add[ni] = a.bias ? a.bias[co] : 0.f;
                 if (a.emb_off >= 0) epi_add[ni] += a.emb_table[(size_t)emb_row * a.emb_stride + a.emb_off + co];   // (conv + bias) + emb == conv + (bias + emb) up to 1 ulp
             }
-            if (PREC != CCDM_PREC_F32) epi_wsc[ni] = k.wscale[co];        // exact power of two
+            if (PREC != CCDM_PREC_F32) epi_wsc[ni] = k.wscale[(nt0 + ni) * 32 + (lane & 31)];        // exact power of two (per packed channel: a phase has its own)
         }
     }
     constexpr int EPS = 36;                        // floats per pixel row of the transpose buffer (16-B aligned rows)
@@ -246,7 +261,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
         const int Cs = cc & 0xffffu, cb = cc >> 16;
         const char* srcb = reinterpret_cast<const char*>(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(T_hi, ch) << 32) |
                                                          (unsigned)__builtin_amdgcn_readlane(T_lo, ch));      // uniform per-sample base
-        const int ups = __builtin_amdgcn_readfirstlane(a.up);   // scalar shift amount (in a vector register the row math below turns vector too)
+        const int ups = UP2 ? 0 : __builtin_amdgcn_readfirstlane(a.up);   // scalar shift amount (in a vector register the row math below turns vector too)
         const int oy0 = ty * TH, ox0 = tx * TW;
         const bool skseg = KS > 1 && ch >= nchunk_main;           // uniform: skip-segment chunk (1x1, no halo needed)
         const int ylo = skseg ? min(oy0, Hc - 1) : 0, yhi = skseg ? min(oy0 + TH - 1, Hc - 1) : Hc - 1;
@@ -336,7 +351,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                                                            (unsigned)__builtin_amdgcn_readlane(T_wlo, ch));
             const unsigned wtap = (unsigned)((sk ? k.cin_pad_skip : k.cin_pad) >> 4) * k.ntiles * 128;
             const unsigned wks = (unsigned)k.ntiles * 128;
-            const unsigned nslab = sk ? KST : KS * KS * KST;
+            const unsigned nslab = sk ? KST : NTAP * KST;
             const unsigned remb = (B_MULTI ? t_ % G : t_) << 4;      // lane offset, 32-bit (hoisted as a 64-bit pair it defeats the saddr form)
 #pragma unroll
             for (int i = 0; i < NITEM_B; ++i) {
@@ -555,13 +570,16 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
             // in front of every tap — runs under the previous step's matrix work.
             constexpr bool PF = MI * NI <= 2;          // the second fragment set fits the register budget
             f16x8 ah[2][MI], al[2][MI], bh[2][NI], bl[2][NI];
-            auto frag_load = [&](const int buf, const int toff, const int bt, const int ks) {
+            auto frag_load_a = [&](const int buf, const int toff, const int ks) {
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
                     const char* p = halo_b + base[mi] + toff + 32 * ks;
                     ah[buf][mi] = *reinterpret_cast<const f16x8*>(p);
                     al[buf][mi] = *reinterpret_cast<const f16x8*>(p + 2 * CK);
                 }
+            };
+            auto frag_load = [&](const int buf, const int toff, const int bt, const int ks) {
+                frag_load_a(buf, toff, ks);
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
                     bh[buf][ni] = bq[((bt * KST + ks) * NI + ni) * 128];
@@ -603,6 +621,31 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                 // skip segment: centre tap only, its weights are staged as B slot 0 (tap split: the centre row's group)
                 if (KSP == 1 || krow == KS / 2)
                     walk(std::integral_constant<int, 1>{}, [&](int) { return (PAD * HWt + PAD) * PIXB; }, [&](int) { return 0; });
+            } else if (UP2 && NI == 4) {
+                // all four phases: halo position (r, c) of the 3x3 neighbourhood is tap (r - dy, c - dx) of phase (dy, dx) when that
+                // lies in its 2x2 window — 16 (position, phase) products per k-step, each A fragment fetched once
+#pragma unroll
+                for (int pos = 0; pos < 9; ++pos)
+#pragma unroll
+                    for (int ks = 0; ks < KST; ++ks) {
+                        const int r = pos / 3, c = pos % 3;
+                        frag_load_a(0, (r * HWt + c) * PIXB, ks);
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) {
+                            const int ta = r - (ni >> 1), tb = c - (ni & 1);
+                            if (ta < 0 || ta > 1 || tb < 0 || tb > 1) continue;
+                            const int bt = ta * 2 + tb;
+                            const f16x8 wh = bq[((bt * KST + ks) * NI + ni) * 128], wl = bq[((bt * KST + ks) * NI + ni) * 128 + 64];
+#pragma unroll
+                            for (int mi = 0; mi < MI; ++mi) {
+                                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[0][mi], wh, acc[mi][ni], 0, 0, 0);
+                                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0][mi], wl, acc[mi][ni], 0, 0, 0);
+                                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[0][mi], wh, acc[mi][ni], 0, 0, 0);
+                            }
+                        }
+                    }
+            } else if (UP2) {
+                walk(std::integral_constant<int, 4>{}, [&](int t) { return ((t >> 1) * HWt + (t & 1)) * PIXB; }, [&](int t) { return t; });
             } else if (KSP > 1) {
                 // tap split: this wave group owns kernel row `krow`
                 walk(std::integral_constant<int, KS>{}, [&](int u) { return (krow * HWt + u) * PIXB; }, [&](int u) { return krow * KS + u; });
@@ -626,20 +669,26 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
                     if (KSP > 1 && ni > 0) __syncthreads();        // the partials of the previous n-tile have been consumed
-                    const int co4 = (nt0 + ni) * 32 + 4 * cq;
+                    const int co4 = tile_of(ni) * 32 + 4 * cq;
+                    const int dy = phase_of(ni) >> 1, dx = phase_of(ni) & 1;
                     const bool cv4 = co4 < a.Cout;
                     // Row j of this wave's float4 pass is output pixel (oy, ox0 + cx + prow): oy and cx are wave-uniform /
                     // compile-time (8 | TW), so for a tile that lies fully inside the image and the channel range the
                     // residual loads and the stores are (scalar row base) + (one thread-constant offset): no per-row VALU.
                     // Ragged tiles take the checked copy.
-                    const bool full = oy0 + TH <= aHout && ox0 + TW <= aWout && (nt0 + ni) * 32 + 32 <= aCout;   // uniform
+                    const int eH = UP2 ? Hc : aHout, eW = UP2 ? Wc : aWout;      // extent of the tile space
+                    const bool full = oy0 + TH <= eH && ox0 + TW <= eW && tile_of(ni) * 32 + 32 <= aCout;   // uniform
                     constexpr int RS_FIRST = MI * 4 > 4 ? 4 : MI * 4;
                     f32x4 rs[MI * 4];
-                    unsigned lane_off = ((unsigned)prow * (unsigned)aCout + (unsigned)co4) << 2;
+                    unsigned lane_off = ((unsigned)(UP2 ? 2 * prow : prow) * (unsigned)aCout + (unsigned)co4) << 2;
                     asm volatile("" : "+v"(lane_off));      // stays a 32-bit offset (hoisted out of the tile loop it becomes a 64-bit pair and the saddr form is lost)
                     auto row_of = [&](const int j) { return oy0 + wave * (MI * 32 / TW) + (j * 8) / TW; };       // uniform
                     auto row_base = [&](const int j) {      // byte offset of pixel (oy, ox0 + cx), channel 0, within the sample
+                        if (UP2) return (unsigned)(((2 * row_of(j) + dy) * aWout + 2 * (ox0 + (j * 8) % TW) + dx) * aCout) << 2;
                         return (unsigned)((row_of(j) * aWout + ox0 + (j * 8) % TW) * aCout) << 2;
+                    };
+                    auto pix_of = [&](const int oy, const int ox) {      // checked copy: pixel index within the sample
+                        return UP2 ? (unsigned)((2 * oy + dy) * aWout + 2 * ox + dx) : (unsigned)(oy * aWout + ox);
                     };
                     // residual rows: the first half is requested before the transpose (its latency hides behind the LDS
                     // writes), the second half behind the first half's stores — all of them live at once together with the
@@ -653,10 +702,10 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                             if (KSP > 1 && j % KSP != krow) continue;
                             if (FULL) rs[j] = load16_uniform_base(reinterpret_cast<const char*>(residn) + row_base(j), lane_off);
                             else {
-                                const int oy = min(row_of(j), aHout - 1), ox = min(ox0 + (j * 8) % TW + prow, aWout - 1);
+                                const int oy = min(row_of(j), eH - 1), ox = min(ox0 + (j * 8) % TW + prow, eW - 1);
                                 const int cc = min(co4, aCout - 4);
                                 rs[j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(residn) +
-                                                                        (((unsigned)(oy * aWout + ox) * (unsigned)aCout + (unsigned)cc) << 2));
+                                                                        ((pix_of(oy, ox) * (unsigned)aCout + (unsigned)cc) << 2));
                             }
                         }
                     };
@@ -691,10 +740,10 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                                 for (int e = 0; e < 4; ++e) { t1[e] += v[e]; t2[e] = fmaf(v[e], v[e], t2[e]); }
                             } else {
                                 const int oy = row_of(j), ox = ox0 + (j * 8) % TW + prow;
-                                if (cv4 && oy < aHout && ox < aWout) {
+                                if (cv4 && oy < eH && ox < eW) {
                                     if (!CCDM_DBG(8))
                                         *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(outn) +
-                                                                  (((unsigned)(oy * aWout + ox) * (unsigned)aCout + (unsigned)co4) << 2)) = v;
+                                                                  ((pix_of(oy, ox) * (unsigned)aCout + (unsigned)co4) << 2)) = v;
 #pragma unroll
                                     for (int e = 0; e < 4; ++e) { t1[e] += v[e]; t2[e] = fmaf(v[e], v[e], t2[e]); }
                                 }
@@ -778,16 +827,21 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
             }
         }
         __syncthreads();
-        for (int i = tid; i < NI * 32; i += NT) {
-            const int ni = i >> 5, l = i & 31;
+        // (sub-pixel form with all four phases in the block: they are n-tiles of ONE 32-channel tile and fold into one partial,
+        //  phase 0..3 in order; with one phase per block each phase leaves its own slot)
+        constexpr int NFOLD = UP2 && NI == 4 ? 4 : 1;
+        for (int i = tid; i < NI / NFOLD * 32; i += NT) {
+            const int ni = (i >> 5) * NFOLD, l = i & 31;
             double t1 = 0.0, t2 = 0.0;
-            for (int w = 0; w < WAVES * KSP; ++w) {
-                t1 += red[((w * NI + ni) * 32 + l) * 2 + 0];
-                t2 += red[((w * NI + ni) * 32 + l) * 2 + 1];
-            }
-            const int co = (nt0 + ni) * 32 + l;
+            for (int f = 0; f < NFOLD; ++f)
+                for (int w = 0; w < WAVES * KSP; ++w) {
+                    t1 += red[((w * NI + ni + f) * 32 + l) * 2 + 0];
+                    t2 += red[((w * NI + ni + f) * 32 + l) * 2 + 1];
+                }
+            const int co = tile_of(ni) * 32 + l;
             if (co < a.Cout) {
-                double* o = a.out_stats + (((size_t)n * k.slices + slice) * a.Cout + co) * 2;
+                const int nslot = UP2 && NI == 1 ? 4 * k.slices : k.slices, slot = UP2 && NI == 1 ? 4 * slice + phase_of(ni) : slice;
+                double* o = a.out_stats + (((size_t)n * nslot + slot) * a.Cout + co) * 2;
                 o[0] = t1; o[1] = t2;
             }
         }
@@ -799,6 +853,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
 static bool tap_split(const ccdm_conv_args& a, const ConvGeo& g);
 static int chunk_ck(const ccdm_conv_args& a, const ConvGeo& g) {
     if ((a.prec & 255) == CCDM_PREC_F32) return 32;
+    if (a.up == 2 && g.TW == 16) return 16;      // four phases of fragments per chunk: 32 KB of B at 16 channels
     const int C = a.C0 + a.C1, SC = a.SC0 + a.SC1;
     const bool ok32 = g.TW < 32 && a.stride == 1 && C % 32 == 0 && (a.C1 == 0 || a.C0 % 32 == 0) &&
                       (!a.skip0 || (SC % 32 == 0 && (a.SC1 == 0 || a.SC0 % 32 == 0)));
@@ -813,7 +868,7 @@ static int chunk_ck(const ccdm_conv_args& a, const ConvGeo& g) {
 
 static bool tap_split(const ccdm_conv_args& a, const ConvGeo& g) {
     // measured: pays at 8x8 images (27 -> 18 us for 128->128), loses at 16x16 (25 -> 33 us with 12-wave blocks)
-    return (a.prec & 255) != CCDM_PREC_F32 && a.ksize == 3 && a.stride == 1 && g.TW == 8 && (a.Cout & 3) == 0;
+    return (a.prec & 255) != CCDM_PREC_F32 && a.ksize == 3 && a.stride == 1 && a.up != 2 && g.TW == 8 && (a.Cout & 3) == 0;
 }
 
 template <int PREC, int CKT, int KS, int STRIDE, int TH, int TW, int WAVES, int MI>
@@ -837,6 +892,14 @@ static int launch_geo(const ConvK& k, const ConvGeo& g, int NI, int ck, dim3 gri
     if (k.a.stride == 2) {
         if constexpr (KS == 3) { if (g.TW == 16) return launch_ni<PREC, CK0, KS, 2, 8, 16, 4, 1>(k, NI, grid, lds, s); }
         return launch_ni<PREC, CK0, KS, 2, 8, 8, 2, 1>(k, NI, grid, lds, s);
+    }
+    if constexpr (PREC != CCDM_PREC_F32 && KS == 3) {
+        if (k.a.up == 2) {          // sub-pixel upsample conv: one n-tile (= phase x channel tile) per block
+            if (g.TW == 16) hipLaunchKernelGGL((k_conv<PREC, CK0, 3, 1, 8, 16, 4, 1, 4, 1, true>), grid, dim3(256), lds, s, k);      // four phases per block
+            else if (ck == 32) hipLaunchKernelGGL((k_conv<PREC, 32, 3, 1, 8, 8, 2, 1, 1, 1, true>), grid, dim3(128), lds, s, k);
+            else hipLaunchKernelGGL((k_conv<PREC, CK0, 3, 1, 8, 8, 2, 1, 1, 1, true>), grid, dim3(128), lds, s, k);
+            return 0;
+        }
     }
     if (g.TW == 32) return launch_ni<PREC, CK0, KS, 1, 8, 32, 4, 2>(k, NI, grid, lds, s);
     if (PREC != CCDM_PREC_F32 && KS == 3 && tap_split(k.a, g)) {       // small-spatial 3x3: kernel rows split over 3 wave groups
@@ -871,8 +934,8 @@ static int launch_prec(const ConvK& k, const ConvGeo& g, int NI, int ck, dim3 gr
 #endif
 }
 
-int conv_slices(int Hout, int Wout, int stride) {
-    const ConvGeo g = conv_geo(Hout, Wout, stride);
+int conv_slices(int Hout, int Wout, int stride, bool up2 = false) {
+    const ConvGeo g = conv_geo(Hout, Wout, stride, up2);
     const int tiles = cdiv(Hout, g.TH) * cdiv(Wout, g.TW);
     // 12 slices for 128x128: with 3 resident blocks per CU, 64 samples x 12 slices = 768 blocks fill the 256 CUs
     // in exactly one round (5.3 tiles per block).  Larger images keep that work per block — one slice per 5.3 tiles (256x512:
@@ -881,11 +944,11 @@ int conv_slices(int Hout, int Wout, int stride) {
     // reads them.  A function of the spatial size only (never of N): sharding the batch must not change the order in which
     // statistics partials are added.
     static const int ovr = getenv("CCDM_SLICES") ? atoi(getenv("CCDM_SLICES")) : 0;     // experiment hook
-    if (ovr > 0 && ovr <= CCDM_STATS_MAX_SLICES && tiles >= ovr) return ovr;
+    if (ovr > 0 && ovr <= CCDM_STATS_FOLD_SLICES && tiles >= ovr) return ovr;
     if (tiles >= 128) return tiles / 16 * 3;
     if (tiles >= 48) return 12;
     if (tiles >= 16) return 8;       // 64x64: 8 slices x 2 tiles (512 blocks, all resident) 28.8 us vs 16 x 1 (1024 blocks, a thin second round) 30.7
-    return tiles < CCDM_STATS_MAX_SLICES ? tiles : CCDM_STATS_MAX_SLICES;
+    return tiles < 16 ? tiles : 16;
 }
 
 static int cin_pad_for(int Cin, int prec) { return prec == CCDM_PREC_F32 ? cdiv(Cin, 32) * 32 : cdiv(Cin, 16) * 16; }
@@ -916,6 +979,12 @@ int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
         CCDM_REQUIRE(a.slices0 >= 1 && (a.C1 == 0 || a.slices1 >= 1), "conv: bad stats slices");
     }
     CCDM_REQUIRE(!a.film || (a.stats0 && a.emb_table), "conv: FiLM needs GroupNorm and an emb table");
+    CCDM_REQUIRE(a.up >= 0 && a.up <= 2, "conv: up = %d", a.up);
+    const bool up2 = a.up == 2;
+    if (up2)
+        CCDM_REQUIRE((a.prec & 255) == CCDM_PREC_F16X3 && a.ksize == 3 && a.stride == 1 && a.Cout % 32 == 0 && !a.resid && !a.skip0 &&
+                     a.Hout == 2 * a.Hin && a.Wout == 2 * a.Win,
+                     "conv: the sub-pixel upsample form needs F16X3, 3x3, stride 1, Cout %% 32 == 0, no residual / fused skip (ccdm_upconv_supported)");
     if (a.skip0) {
         CCDM_REQUIRE(a.stride == 1 && !a.up && a.skip_w, "conv: fused skip needs stride 1, no upsample, packed skip_w");
         CCDM_REQUIRE(a.SC0 % 4 == 0 && a.SC1 % 4 == 0 && a.SC0 > 0, "conv: skip channels %d/%d must be multiples of 4", a.SC0, a.SC1);
@@ -935,11 +1004,14 @@ int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
     k.cin_pad = cin_pad_for(C, prec);
     k.cin_pad_skip = a.skip0 ? cin_pad_for(a.SC0 + a.SC1, prec) : 0;
     int NI;
-    conv_ntiles(a.Cout, &k.ntiles, &NI);
-    const ConvGeo g = conv_geo(a.Hout, a.Wout, a.stride);
+    conv_ntiles(up2 ? 4 * a.Cout : a.Cout, &k.ntiles, &NI);
+    // the sub-pixel form tiles the low-resolution input space
+    const int tH = up2 ? a.Hin : a.Hout, tW = up2 ? a.Win : a.Wout;
+    const ConvGeo g = conv_geo(tH, tW, a.stride, up2);
     // small spatial stages have few pixel tiles: spread the output-channel tiles over blocks instead;
     // wide tiles take at most 2 n-tiles per block (register budget of the staged B chunk)
-    if (g.TW < 32) NI = 1;
+    if (up2) NI = g.TW == 16 ? 4 : 1;
+    else if (g.TW < 32) NI = 1;
     else {
         // two n-tiles per block share one staged halo (half the staging work) but need 236 VGPRs and 64 KB of LDS (two blocks
         // per CU): worth it only when there are blocks to spare.  Measured at the 32x32 stage (64 samples x 4 tiles): one n-tile
@@ -948,17 +1020,19 @@ int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
         const long blocks2 = (long)a.N * conv_slices(a.Hout, a.Wout, a.stride) * (k.ntiles / 2);
         NI = (k.ntiles % 2 == 0 && blocks2 >= 512) ? 2 : 1;
     }
-    k.tiles_x = cdiv(a.Wout, g.TW);
-    k.tiles_y = cdiv(a.Hout, g.TH);
-    k.slices = conv_slices(a.Hout, a.Wout, a.stride);
-    k.wscale = reinterpret_cast<const float*>(static_cast<const char*>(a.w) + packed_frag_bytes(a.Cout, C, a.ksize, prec));
-    if (a.out_stats) CCDM_REQUIRE(a.out_slices == k.slices, "conv: out_slices %d != %d", a.out_slices, k.slices);
+    k.tiles_x = cdiv(tW, g.TW);
+    k.tiles_y = cdiv(tH, g.TH);
+    k.slices = conv_slices(tH, tW, a.stride, up2);
+    k.wscale = reinterpret_cast<const float*>(static_cast<const char*>(a.w) +
+                                              (up2 ? packed_frag_bytes(4 * a.Cout, C, 2, prec) : packed_frag_bytes(a.Cout, C, a.ksize, prec)));
+    const int want_slices = (up2 && NI == 1 ? 4 : 1) * k.slices;      // one phase per block: every (slice, phase) pair leaves a partial
+    if (a.out_stats) CCDM_REQUIRE(a.out_slices == want_slices, "conv: out_slices %d != %d", a.out_slices, want_slices);
     const int HP = ((g.TH - 1) * a.stride + a.ksize) * ((g.TW - 1) * a.stride + a.ksize);
     const int ck = chunk_ck(a, g);
     {   // core halo items need no per-lane padding mask when every tile column and every channel quad exists (see ConvK)
         const int SC = a.SC0 + a.SC1;
         const bool chan_ok = a.C0 % ck == 0 && a.C1 % ck == 0 && (!a.skip0 || (a.SC0 % ck == 0 && a.SC1 % ck == 0 && SC > 0));
-        k.core_unmasked = (a.stride == 1 && Wc % g.TW == 0 && chan_ok) ? 1 : 0;
+        k.core_unmasked = (a.stride == 1 && (up2 ? a.Win : Wc) % g.TW == 0 && chan_ok) ? 1 : 0;
     }
     CCDM_REQUIRE(a.C1 == 0 || a.C0 % ck == 0, "conv: first source has %d channels; a concatenated input must split at a multiple of the %d-channel chunk", a.C0, ck);
     CCDM_REQUIRE(a.SC1 == 0 || a.SC0 % ck == 0, "conv: first skip source has %d channels; a concatenated input must split at a multiple of the %d-channel chunk", a.SC0, ck);
@@ -966,7 +1040,7 @@ int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
                  k.cin_pad, k.cin_pad_skip, ck);
     size_t lds = (size_t)HP * (prec == CCDM_PREC_F32 ? 33 * 4 : ck * 4 + 16);
     lds = (lds + 15) / 16 * 16;
-    if (prec != CCDM_PREC_F32) lds += (size_t)a.ksize * a.ksize * (ck / 16) * NI * 128 * 16;     // staged B chunk
+    if (prec != CCDM_PREC_F32) lds += (size_t)(up2 ? 4 : a.ksize * a.ksize) * (ck / 16) * NI * 128 * 16;     // staged B chunk
     const int ksp = tap_split(a, g) ? 3 : 1;
     const size_t red = (size_t)g.waves * ksp * NI * 32 * 16;
     if (lds < red) lds = red;
@@ -995,6 +1069,14 @@ int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
 extern "C" int ccdm_conv_slices(int Hout, int Wout, int stride, int ksize) {
     (void)ksize;
     return ccdm::conv_slices(Hout, Wout, stride);
+}
+
+extern "C" int ccdm_upconv_supported(int Cin, int Cout, int prec) {
+    return prec == CCDM_PREC_F16X3 && Cin > 0 && Cin % 4 == 0 && Cout > 0 && Cout % 32 == 0;
+}
+
+extern "C" int ccdm_upconv_slices(int Hin, int Win) {
+    return (ccdm::conv_geo(Hin, Win, 1, true).TW == 16 ? 1 : 4) * ccdm::conv_slices(Hin, Win, 1, true);
 }
 
 extern "C" int ccdm_debug_read_timeline(unsigned long long* host, int n) {
@@ -1078,4 +1160,29 @@ extern "C" size_t ccdm_pack_conv_weight_ex(const float* oihw, int Cout, int Cin,
                         o[base + 64 * 8 + (size_t)l * 8 + j] = lo;
                     }
     return total;
+}
+
+
+// Sub-pixel form of Upsample(nearest x2) + conv 3x3 (include/ccdm_hip.h, `up = 2`): phase (dy, dx) sees the low-resolution 2x2
+// window rows {y+dy-1, y+dy}; kernel row u of the 3x3 lands on window row a = (dy + u + 1) / 2 - dy  (dy=0: u=0 -> 0, u=1,2 -> 1;
+// dy=1: u=0,1 -> 0, u=2 -> 1), columns alike.  Taps that share a window cell are added in fp64 and rounded once to fp32; the result
+// is packed as a 2x2 conv with 4*Cout output channels, channel = (4 * (co / 32) + phase) * 32 + co % 32 (the four phases of a
+// 32-channel tile are adjacent n-tiles).
+extern "C" size_t ccdm_pack_upconv_weight(const float* oihw, int Cout, int Cin, int prec, void* out) {
+    if (!ccdm_upconv_supported(Cin, Cout, prec)) { ccdm::fail("pack_upconv: Cin=%d Cout=%d prec=%d not supported", Cin, Cout, prec); return 0; }
+    if (!out) return ccdm_pack_conv_weight_ex(nullptr, 4 * Cout, Cin, 2, prec, nullptr, nullptr);
+    std::vector<float> w2((size_t)4 * Cout * Cin * 4);
+    for (int ph = 0; ph < 4; ++ph) {
+        const int dy = ph >> 1, dx = ph & 1;
+        for (int co = 0; co < Cout; ++co)
+            for (int ci = 0; ci < Cin; ++ci) {
+                double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+                for (int u = 0; u < 3; ++u)
+                    for (int v = 0; v < 3; ++v)
+                        acc[(dy + u + 1) / 2 - dy][(dx + v + 1) / 2 - dx] += (double)oihw[(((size_t)co * Cin + ci) * 3 + u) * 3 + v];
+                float* d = &w2[(((size_t)(4 * (co / 32) + ph) * 32 + co % 32) * Cin + ci) * 4];
+                d[0] = (float)acc[0][0]; d[1] = (float)acc[0][1]; d[2] = (float)acc[1][0]; d[3] = (float)acc[1][1];
+            }
+    }
+    return ccdm_pack_conv_weight_ex(w2.data(), 4 * Cout, Cin, 2, prec, nullptr, out);
 }

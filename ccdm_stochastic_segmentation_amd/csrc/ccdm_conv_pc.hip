@@ -503,7 +503,7 @@ bool conv_pc_eligible(const ConvK& k, const ConvGeo& g, int NI) {
     // exposes every block's prologue and tail that k_conv's three co-resident blocks hide.
     static const int on = getenv("CCDM_PC") ? atoi(getenv("CCDM_PC")) : 0;
     const ccdm_conv_args& a = k.a;
-    if (!on || (a.prec & ~255)) return false;
+    if (!on || (a.prec & ~255) || a.up == 2) return false;
     if ((a.prec & 255) != CCDM_PREC_F16X3 || a.ksize != 3 || a.stride != 1 || g.TW != 32) return false;
     if ((a.Cout & 3) != 0) return false;
     const int nchunk = (k.cin_pad + k.cin_pad_skip) / PC_CK;

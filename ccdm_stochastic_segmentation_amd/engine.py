@@ -18,6 +18,8 @@ import torch
 from . import hip
 from .unet_spec import GN_EPS, UNetSpec
 
+_NO_SUBPIXEL = bool(int(os.environ.get("CCDM_NO_SUBPIXEL", "0")))     # same-box A/B hook: Upsample convs in the direct (9-tap) form
+
 
 @dataclass
 class DevTensor:
@@ -89,11 +91,11 @@ class SamplerEngine:
         self._keep.append(d)
         return d
 
-    def _act(self, C_: int, h: int, w: int, stats: bool, stride: int = 1) -> DevTensor:
+    def _act(self, C_: int, h: int, w: int, stats: bool, stride: int = 1, subpixel: bool = False) -> DevTensor:
         buf = self._dev((self.N, h, w, C_))
         t = DevTensor(buf, C_, h, w)
         if stats:
-            t.slices = self.lib.ccdm_conv_slices(h, w, stride, 3)
+            t.slices = self.lib.ccdm_upconv_slices(h // 2, w // 2) if subpixel else self.lib.ccdm_conv_slices(h, w, stride, 3)
             t.stats = self._dev((self.N, t.slices, C_, 2), torch.float64)
         return t
 
@@ -102,12 +104,12 @@ class SamplerEngine:
         most STATS_MAX_SLICES, so fold them right behind the producer (fixed order, independent of N)."""
         if t.stats is None or t.slices <= hip.STATS_MAX_SLICES:
             return
-        folded = self._dev((self.N, hip.STATS_MAX_SLICES, t.C, 2), torch.float64)
-        hip.check(self.lib.ccdm_engine_add_stats_fold(self._handle, t.stats.data_ptr(), self.N, t.slices, t.C, hip.STATS_MAX_SLICES,
+        folded = self._dev((self.N, hip.STATS_FOLD_SLICES, t.C, 2), torch.float64)
+        hip.check(self.lib.ccdm_engine_add_stats_fold(self._handle, t.stats.data_ptr(), self.N, t.slices, t.C, hip.STATS_FOLD_SLICES,
                                                       folded.data_ptr()), "engine_add_stats_fold")
         self.op_names.append("stats_fold")
         self.op_info.append(dict(kind="stats_fold", name="stats_fold", io_bytes=0, gn_read_bytes=0, weight_bytes=0, flop=0))
-        t.stats, t.slices = folded, hip.STATS_MAX_SLICES
+        t.stats, t.slices = folded, hip.STATS_FOLD_SLICES
 
     # ------------------------------------------------------------------ op emission
     def _conv(self, src: Sequence[DevTensor], wkey: str, cout: int, ksize: int, *, gn: Optional[str] = None,
@@ -131,14 +133,17 @@ class SamplerEngine:
             absmax = np.maximum(np.abs(w.reshape(cout, -1)).max(1), np.abs(ws).max(1)).astype(np.float32)
             skip_w = self._upload(hip.pack_conv_weight(ws.reshape(cout, -1, 1, 1), 1, self.prec, absmax))
             bias_np = bias_np + sd[skip_key + ".bias"].numpy()
-        wdev = self._upload(hip.pack_conv_weight(w, ksize, self.prec, absmax))
+        # Upsample + conv 3x3 runs in sub-pixel form (4 taps of the low-resolution input per output pixel instead of 9) where built
+        subpixel = bool(up) and ksize == 3 and stride == 1 and resid is None and skip_src is None and not _NO_SUBPIXEL and \
+            bool(self.lib.ccdm_upconv_supported(cin, cout, self.prec))
+        wdev = self._upload(hip.pack_upconv_weight(w, self.prec) if subpixel else hip.pack_conv_weight(w, ksize, self.prec, absmax))
         bias = self._upload(bias_np)
         hin, win = a.h, a.w
         hc, wc = (2 * hin, 2 * win) if up else (hin, win)
         pad = ksize // 2
         hout = (hc + 2 * pad - ksize) // stride + 1
         wout = (wc + 2 * pad - ksize) // stride + 1
-        out = self._act(cout, hout, wout, stats, stride)
+        out = self._act(cout, hout, wout, stats, stride, subpixel)
         args = hip.ConvArgs()
         args.in0, args.C0 = a.ptr, a.C
         args.in1, args.C1 = (b.ptr, b.C) if b else (0, 0)
@@ -151,7 +156,7 @@ class SamplerEngine:
         args.eps, args.act = GN_EPS, act
         args.film, args.film_off = (1, film_off) if film_off >= 0 else (0, 0)
         args.N, args.Hin, args.Win, args.Hout, args.Wout = self.N, hin, win, hout, wout
-        args.ksize, args.stride, args.up = ksize, stride, int(up)
+        args.ksize, args.stride, args.up = ksize, stride, (2 if subpixel else int(up))
         args.w, args.bias, args.Cout, args.prec = wdev.data_ptr(), bias.data_ptr(), cout, self.prec
         args.emb_table, args.emb_stride, args.emb_off = self.emb_table.data_ptr(), self.E, emb_off
         args.emb_row_of_sample = self.rowmap.data_ptr()

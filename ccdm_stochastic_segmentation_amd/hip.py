@@ -24,8 +24,9 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 ACT_NONE, ACT_SILU = 0, 1
 PREC_F32, PREC_F16X3 = 0, 1
 STEP_SAMPLE, STEP_LAST_CONFIDENCE, STEP_LAST_MAJORITY, STEP_LAST_KEEP, STEP_SOFTMAX_ONLY = 0, 1, 2, 3, 4
-STATS_MAX_SLICES = 16
-ABI_VERSION = 2          # CCDM_ABI_VERSION of include/ccdm_hip.h
+STATS_MAX_SLICES = 32       # CCDM_STATS_MAX_SLICES: what a GroupNorm consumer reads
+STATS_FOLD_SLICES = 16      # CCDM_STATS_FOLD_SLICES: what the engine folds a larger slice count to
+ABI_VERSION = 3          # CCDM_ABI_VERSION of include/ccdm_hip.h
 
 
 class ConvArgs(C.Structure):
@@ -84,6 +85,9 @@ SIGNATURES = {
     "ccdm_last_error_string": (C.c_char_p, []),
     "ccdm_gn_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ccdm_conv_slices": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ccdm_upconv_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "ccdm_upconv_slices": (C.c_int, [C.c_int, C.c_int]),
+    "ccdm_pack_upconv_weight": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ccdm_conv2d": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "ccdm_stats_fold": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ccdm_norm_qkv_attention_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
@@ -226,6 +230,21 @@ def pack_conv_weight(w, ksize: int, prec: int = PREC_F32, cout_absmax=None):
         raise CcdmHipError("pack_conv_weight: " + last_error())
     out = np.empty(nbytes, dtype=np.uint8)
     lib.ccdm_pack_conv_weight_ex(w.ctypes.data, cout, cin, ksize, prec, amp, out.ctypes.data)
+    return out
+
+
+def pack_upconv_weight(w, prec: int = PREC_F16X3):
+    """Upsample's 3x3 conv weight [Cout,Cin,3,3] -> packed sub-pixel form for ccdm_conv_args.up = 2 (host-side, no GPU needed)."""
+    import numpy as np
+    lib = load()
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    cout, cin = int(w.shape[0]), int(w.shape[1])
+    assert w.shape == (cout, cin, 3, 3), w.shape
+    nbytes = lib.ccdm_pack_upconv_weight(None, cout, cin, prec, None)
+    if nbytes == 0:
+        raise CcdmHipError("pack_upconv_weight: " + last_error())
+    out = np.empty(nbytes, dtype=np.uint8)
+    lib.ccdm_pack_upconv_weight(w.ctypes.data, cout, cin, prec, out.ctypes.data)
     return out
 
 

@@ -22,9 +22,10 @@
 extern "C" {
 #endif
 
-#define CCDM_ABI_VERSION 2
+#define CCDM_ABI_VERSION 3
 #define CCDM_MAX_CHANNELS 1024      /* max C0+C1 of a GroupNorm'ed conv input */
-#define CCDM_STATS_MAX_SLICES 16    /* partial-statistics slices per sample a GroupNorm consumer reads (more: ccdm_stats_fold) */
+#define CCDM_STATS_MAX_SLICES 32    /* partial-statistics slices per sample a GroupNorm consumer reads (more: ccdm_stats_fold) */
+#define CCDM_STATS_FOLD_SLICES 16   /* what ccdm_stats_fold reduces a larger slice count to */
 
 int ccdm_version(void);
 const char* ccdm_last_error_string(void);
@@ -67,7 +68,9 @@ typedef struct ccdm_conv_args {
     int32_t N, Hin, Win, Hout, Wout;
     int32_t ksize;                                  /* 1 or 3 (pad = ksize/2) */
     int32_t stride;                                 /* 1 or 2 */
-    int32_t up;                                     /* 1: nearest x2 upsample of the input on load */
+    int32_t up;                                     /* 1: nearest x2 upsample of the input on load (weights: ccdm_pack_conv_weight);
+                                                     * 2: the same operator in sub-pixel form (weights: ccdm_pack_upconv_weight,
+                                                     *    out_slices = ccdm_upconv_slices) — see below */
     /* weights, packed by ccdm_pack_conv_weight for `prec` */
     const void* w; const float* bias; int32_t Cout; int32_t prec;
     /* epilogue */
@@ -90,7 +93,18 @@ typedef struct ccdm_conv_args {
  * CCDM_STATS_MAX_SLICES (one slice = one workgroup per sample: 256x512 -> 96, 512x1024 -> 384): fold them with
  * ccdm_stats_fold before handing them to a GroupNorm consumer. */
 int ccdm_conv_slices(int Hout, int Wout, int stride, int ksize);
-/* out[n][j] = sum of in[n][i] over i in [j*S_in/S_out, (j+1)*S_in/S_out), ascending (fixed order); S_out <= CCDM_STATS_MAX_SLICES */
+/* Upsample (nearest x2) + conv 3x3 in sub-pixel form (unet.py:106-116), `up = 2`:
+ *   out(2y+dy, 2x+dx) = sum over a,b in {0,1} of W'[dy,dx][a,b] . in(y+dy-1+a, x+dx-1+b),
+ *   W'[dy][..][a] = the 3x3 kernel rows that land on low-resolution row y+dy-1+a  (dy=0: {r0}, {r1+r2}; dy=1: {r0+r1}, {r2}; columns alike):
+ * four 2x2 convs of the LOW-resolution input — 4 instead of 9 taps per output pixel and a quarter of the staged halo.  The four
+ * phases run as adjacent output-channel tiles of one launch (one block computes all four from one staged halo).  Needs CCDM_PREC_F16X3, ksize 3, stride 1, Cout % 32 == 0, no residual / fused
+ * skip (ccdm_upconv_supported).  Sums of kernel taps are formed in fp64 and rounded once to fp32 before the fp16 split: results
+ * differ from `up = 1` by fp32 rounding only.  out_slices = ccdm_upconv_slices(Hin, Win): the slices of the low-resolution
+ * tiling (x 4 for inputs narrower than 16 pixels, where every phase runs in its own block); a function of the spatial size only. */
+int ccdm_upconv_supported(int Cin, int Cout, int prec);
+int ccdm_upconv_slices(int Hin, int Win);
+size_t ccdm_pack_upconv_weight(const float* oihw /*[Cout,Cin,3,3]*/, int Cout, int Cin, int prec, void* out);
+/* out[n][j] = sum of in[n][i] over i in [j*S_in/S_out, (j+1)*S_in/S_out), ascending (fixed order); S_out <= CCDM_STATS_MAX_SLICES (the engine folds to CCDM_STATS_FOLD_SLICES) */
 int ccdm_stats_fold(const double* in /*dev [N,S_in,C,2]*/, int N, int S_in, int C, int S_out, double* out /*dev [N,S_out,C,2]*/, void* stream);
 int ccdm_conv2d(const ccdm_conv_args* a, void* stream);
 

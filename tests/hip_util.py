@@ -49,7 +49,8 @@ def conv2d(srcs, weight, bias, ksize, *, stats=None, gamma=None, beta=None, act=
         absmax = np.maximum(np.abs(w.reshape(cout, -1)).max(1), np.abs(sw).max(1)).astype(np.float32)
         swdev = torch.from_numpy(hip.pack_conv_weight(sw.reshape(cout, -1, 1, 1), 1, prec, absmax)).to(DEV)
         bias = bias + np.asarray(sb, dtype=np.float32)
-    wdev = torch.from_numpy(hip.pack_conv_weight(w, ksize, prec, absmax)).to(DEV)
+    # up: False / True (upsample on load) / 2 (the same operator in sub-pixel form, include/ccdm_hip.h)
+    wdev = torch.from_numpy(hip.pack_upconv_weight(w, prec) if up == 2 else hip.pack_conv_weight(w, ksize, prec, absmax)).to(DEV)
     bdev = torch.as_tensor(bias).to(DEV)
     Hc, Wc = (2 * Hin, 2 * Win) if up else (Hin, Win)
     pad = ksize // 2
@@ -95,7 +96,7 @@ def conv2d(srcs, weight, bias, ksize, *, stats=None, gamma=None, beta=None, act=
     args.out = out.data_ptr()
     ost = None
     if want_stats:
-        S = lib.ccdm_conv_slices(Hout, Wout, stride, ksize)
+        S = lib.ccdm_upconv_slices(Hin, Win) if up == 2 else lib.ccdm_conv_slices(Hout, Wout, stride, ksize)
         ost = torch.empty((N, S, cout, 2), dtype=torch.float64, device=DEV)
         args.out_stats, args.out_slices = ost.data_ptr(), S
     hip.check(lib.ccdm_conv2d(C.byref(args), 0), "conv2d")

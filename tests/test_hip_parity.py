@@ -128,6 +128,41 @@ def test_conv(U, case, prec):
     np.testing.assert_allclose(st[..., 1].numpy(), (gd * gd).sum((2, 3)).numpy(), rtol=2e-6, atol=0)
 
 
+@pytest.mark.parametrize("cin,cout,H,W", [(32, 32, 64, 64), (64, 64, 32, 32), (96, 96, 16, 16), (128, 128, 8, 8), (32, 64, 20, 44), (36, 32, 12, 8),
+                                            (64, 64, 72, 96)])
+def test_upsample_conv_subpixel_form(U, cin, cout, H, W):
+    """Upsample(nearest x2) + conv 3x3 (unet.py:106-116) as four 2x2 convs of the low-resolution input (`up = 2`): equals the
+    direct operator up to fp32 rounding, its statistics partials (one per (slice, phase)) add up to the statistics of the output,
+    and it agrees with the direct HIP form (`up = 1`)."""
+    rng = np.random.default_rng(cin + cout + H + W)
+    N = 3
+    x = rnd(rng, N, cin, H, W) * 1.5 + 0.3
+    w = rnd(rng, cout, cin, 3, 3) / np.sqrt(cin * 9)
+    b = rnd(rng, cout, scale=0.1)
+    ref = F.conv2d(F.interpolate(x.double(), scale_factor=2, mode="nearest"), w.double(), b.double(), padding=1)
+    xs = U.nhwc(x)
+    out, ost = U.conv2d([xs], w.numpy(), b.numpy(), 3, up=2, prec=hip.PREC_F16X3)
+    assert ost.shape[1] == hip.load().ccdm_upconv_slices(H, W)
+    got = U.bchw(out)
+    np.testing.assert_allclose(got.numpy(), ref.float().numpy(), rtol=0, atol=2e-5)
+    direct, _ = U.conv2d([xs], w.numpy(), b.numpy(), 3, up=True, prec=hip.PREC_F16X3)
+    np.testing.assert_allclose(got.numpy(), U.bchw(direct).numpy(), rtol=0, atol=1e-5)
+    st = ost.cpu().sum(1)
+    gd = got.double()
+    np.testing.assert_allclose(st[..., 0].numpy(), gd.sum((2, 3)).numpy(), rtol=0, atol=2e-6 * gd.abs().sum((2, 3)).max().item())
+    np.testing.assert_allclose(st[..., 1].numpy(), (gd * gd).sum((2, 3)).numpy(), rtol=2e-6, atol=0)
+
+
+def test_upsample_conv_subpixel_form_refusals(U):
+    lib = hip.load()
+    assert lib.ccdm_upconv_supported(64, 64, hip.PREC_F16X3) == 1
+    assert lib.ccdm_upconv_supported(64, 48, hip.PREC_F16X3) == 0 and lib.ccdm_upconv_supported(64, 64, hip.PREC_F32) == 0
+    x = U.nhwc(torch.randn(1, 32, 8, 8))
+    w = np.zeros((32, 32, 3, 3), np.float32)
+    with pytest.raises(hip.CcdmHipError, match="sub-pixel"):
+        U.conv2d([x], w, np.zeros(32, np.float32), 3, up=2, prec=hip.PREC_F16X3, resid=torch.zeros(1, 16, 16, 32, device="cuda"))
+
+
 @pytest.mark.parametrize("prec", PRECS, ids=PREC_IDS)
 @pytest.mark.parametrize("c0,c1,cout,H,W", [(64, 32, 32, 32, 32), (128, 96, 96, 16, 16), (256, 0, 128, 8, 8), (64, 0, 32, 40, 24)])
 def test_conv_with_fused_skip(U, prec, c0, c1, cout, H, W):

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(hip.SIGNATURES), declared ^ set(hip.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ccdm_version() == hip.ABI_VERSION == 2
+    assert lib.ccdm_version() == hip.ABI_VERSION == 3
     assert ctypes.sizeof(hip.ConvArgs) % 8 == 0 and ctypes.sizeof(hip.PostArgs) % 8 == 0
 
 
@@ -78,6 +78,37 @@ def test_pack_conv_weight_layout():
     assert hip.load().ccdm_conv_slices(128, 128, 1, 3) == 12
     assert hip.load().ccdm_conv_slices(16, 16, 1, 3) == 2
     assert hip.load().ccdm_conv_slices(8, 8, 1, 3) == 1
+
+
+def test_pack_upconv_weight_is_the_phase_summed_2x2_kernel():
+    """ccdm_pack_upconv_weight (include/ccdm_hip.h, `up = 2`): Upsample + conv 3x3 (unet.py:106-116) as four 2x2 kernels — the 3x3 taps
+    that fall on one low-resolution pixel added in fp64, rounded once, packed as a 2x2 conv with n-tile = 4 * (channel tile) + phase.  The
+    numpy restatement below also checks the operator identity itself against F.interpolate + F.conv2d."""
+    import torch.nn.functional as F
+    rng = np.random.default_rng(5)
+    cout, cin = 64, 8
+    w = rng.standard_normal((cout, cin, 3, 3)).astype(np.float32)
+    w2 = np.zeros((4, cout, cin, 2, 2), np.float64)
+    for dy in range(2):
+        for dx in range(2):
+            for u in range(3):
+                for v in range(3):
+                    w2[2 * dy + dx, :, :, (dy + u + 1) // 2 - dy, (dx + v + 1) // 2 - dx] += w[:, :, u, v]
+    # packed channel = (4 * (co // 32) + phase) * 32 + co % 32: the four phases of a 32-channel tile are adjacent n-tiles
+    w2f = w2.astype(np.float32).reshape(4, cout // 32, 32, cin, 2, 2).transpose(1, 0, 2, 3, 4, 5).reshape(4 * cout, cin, 2, 2)
+    assert np.array_equal(hip.pack_upconv_weight(w), hip.pack_conv_weight(w2f, 2, hip.PREC_F16X3))
+    assert hip.load().ccdm_upconv_slices(64, 64) == 8 and hip.load().ccdm_upconv_slices(8, 8) == 4
+    assert hip.load().ccdm_upconv_supported(cin, 48, hip.PREC_F16X3) == 0
+    # operator identity: out(2y+dy, 2x+dx) = sum_ab W'[dy,dx][a,b] in(y+dy-1+a, x+dx-1+b), zero outside the image
+    x = torch.from_numpy(rng.standard_normal((1, cin, 5, 7)))
+    ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), torch.from_numpy(w).double(), padding=1)
+    xp = F.pad(x, (1, 1, 1, 1))
+    got = torch.zeros_like(ref)
+    for dy in range(2):
+        for dx in range(2):
+            ph = F.conv2d(xp, torch.from_numpy(w2[2 * dy + dx]))             # [1,cout,H+1,W+1]: window origin (y-1+., x-1+.)
+            got[:, :, dy::2, dx::2] = ph[:, :, dy:dy + 5, dx:dx + 7]
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=0, atol=1e-12)
 
 
 def test_missing_library_is_a_hard_error(monkeypatch, tmp_path):
