@@ -150,6 +150,8 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
     const bool has_gn = a.stats0 != nullptr;
     const int dbg = a.prec >> 8;          // ablation switches for tools/bench_conv.py (CCDM_ABLATION builds only)
     (void)dbg;
+    int tl = 0;
+    CCDM_STAMP(12);
 
     const int aWout = a.Wout, aCout = a.Cout, aHout = a.Hout, aWin = a.Win;
     const size_t in_px = (size_t)a.Hin * a.Win;
@@ -177,19 +179,23 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
     // per-lane epilogue constants of output channel (n-tile, lane & 31): bias (+ emb row) and the power of two that undoes
     // the weight / activation pre-scales.  Fetched once per block — inside the tile loop their L2 latency sat in every
     // epilogue's critical path.
-    float epi_add[NI], epi_wsc[NI];
+    //   The block's small loads — these constants and everything GroupNorm's (scale, shift) table needs — are all ISSUED here, ahead
+    //   of the first halo request, unconditionally (clamped / dummy addresses: no branch, hence no waitcnt drain at a join), and
+    //   consumed only after that request is on its way: vector memory returns in order, so they come back first and the fp64
+    //   finalisation runs while the halo is in flight.  (Consumed in place they cost the block two to three dependent round trips
+    //   before its first commit: 3700 of the 7300 prologue cycles of an 8x8 block, whose chain is the launch time.)
+    float epi_add[NI], epi_wsc[NI], raw_bias[NI], raw_emb[NI];
+    const float* const dummyf = reinterpret_cast<const float*>(a.w);
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
-        const int co = tile_of(ni) * 32 + (lane & 31);              // real output channel
-        epi_add[ni] = 0.f; epi_wsc[ni] = 1.0f;
-        if (co < a.Cout) {
-            if (krow == 0) {                        // bias (+emb) enters once, through row group 0's partial
-                epi_add[ni] = a.bias ? a.bias[co] : 0.f;
-                if (a.emb_off >= 0) epi_add[ni] += a.emb_table[(size_t)emb_row * a.emb_stride + a.emb_off + co];   // (conv + bias) + emb == conv + (bias + emb) up to 1 ulp
-            }
-            if (PREC != CCDM_PREC_F32) epi_wsc[ni] = k.wscale[(nt0 + ni) * 32 + (lane & 31)];        // exact power of two (per packed channel: a phase has its own)
-        }
+        const int co = min(tile_of(ni) * 32 + (lane & 31), a.Cout - 1);              // real output channel (clamped; masked below)
+        raw_bias[ni] = *(a.bias ? a.bias + co : dummyf);
+        raw_emb[ni] = *(a.emb_off >= 0 ? a.emb_table + (size_t)emb_row * a.emb_stride + a.emb_off + co : dummyf);
+        epi_wsc[ni] = PREC != CCDM_PREC_F32 ? k.wscale[min((nt0 + ni) * 32 + (lane & 31), k.ntiles * 32 - 1)] : 1.0f;   // exact power of two (per packed channel: a phase has its own)
     }
+    GnPrefetch gpf;
+    gn_prefetch(a, has_gn, n, emb_row, min(tid, C - 1), a.w, gpf);
+    __builtin_amdgcn_sched_barrier(0);             // the requests above stay above the halo request
     constexpr int EPS = 36;                        // floats per pixel row of the transpose buffer (16-B aligned rows)
     float* epi = reinterpret_cast<float*>(halo_b) + wave_all * (MI * 32 * EPS);      // [krow][wave][MI*32][EPS]
 
@@ -293,7 +299,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                     const int iyc = min(max(iy, ylo), yhi);
                     const unsigned sy = (unsigned)(iyc >> ups);
                     if constexpr (ROW_UNIFORM) reg[d][i] = load16_uniform_base(srcb + (size_t)(sy * rowb), colb);
-                    else reg[d][i] = *reinterpret_cast<const f32x4*>(srcb + (sy * rowb + colb));
+                    else reg[d][i] = load16_global(srcb + (sy * rowb + colb));
                     rowmask[d] |= (rok ? 1u : 0u) << i;
                 }
             }
@@ -307,7 +313,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                 const bool ok = cok & (e < (unsigned)EDGE_ITEMS) & ((unsigned)iy < (unsigned)Hc) & ((unsigned)ix < (unsigned)Wc);
                 const int iyc = min(max(iy, ylo), yhi), ixc = min(max(ix, xlo), xhi);
                 const unsigned sy = (unsigned)(iyc >> ups), sx = (unsigned)(ixc >> ups);
-                reg[d][NCORE + j] = *reinterpret_cast<const f32x4*>(srcb + (size_t)(sy * rowb + ((sx * (unsigned)Cs + cq) << 2)));
+                reg[d][NCORE + j] = load16_global(srcb + (size_t)(sy * rowb + ((sx * (unsigned)Cs + cq) << 2)));
                 evalid[d] |= (ok ? 1u : 0u) << j;
             }
         } else {
@@ -329,7 +335,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                 const int iyc = min(max(iy, 0), Hc - 1), ixc = min(max(ix, 0), Wc - 1);
                 const int sy = iyc >> ups, sx = ixc >> ups;
                 const unsigned off = ((unsigned)(sy * aWin + sx) * (unsigned)Cs + cq) << 2;      // bytes within the sample
-                reg[d][i] = *reinterpret_cast<const f32x4*>(srcb + off);
+                reg[d][i] = load16_global(srcb + off);
                 valid[d] |= (ok ? 1u : 0u) << i;
                 hy += DHY; hx += DHX;
                 if (hx >= (unsigned)HWt) { hx -= HWt; hy += 1; }
@@ -478,7 +484,6 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
     };
 
     f32x16 acc[MI][NI];
-    int tl = 0;
     CCDM_STAMP(1);
     // (tile, chunk) walk of this block — tile = slice, slice + slices, ... — carried as scalar counters: the current
     // iteration's (chunk, ty, tx) and, one step ahead, the prefetch's (no divisions in the loop)
@@ -492,19 +497,30 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
     int chunk = 0, cur_ty = slice / k.tiles_x, cur_tx = slice % k.tiles_x;
     int pf_ch = 0, pf_ty = cur_ty, pf_tx = cur_tx;
     // prologue: fill every register set (sets beyond the last iteration request clamped addresses: harmless, branch-free)
-    if (n_iter > 0) {
-        issue(std::integral_constant<int, 0>{}, pf_ch, pf_ty, pf_tx);
-        if constexpr (DEEP_B) issueB(std::integral_constant<int, 0>{}, pf_ch);
+    // (a launch always has n_iter >= 1: slices <= tiles)
+    issue(std::integral_constant<int, 0>{}, pf_ch, pf_ty, pf_tx);
+    if constexpr (DEEP_B) issueB(std::integral_constant<int, 0>{}, pf_ch);
+    advance(pf_ch, pf_ty, pf_tx);
+    if constexpr (DEPTH > 1) {
+        issue(std::integral_constant<int, 1>{}, pf_ch, pf_ty, pf_tx);
+        if constexpr (DEEP_B) issueB(std::integral_constant<int, 1>{}, pf_ch);
         advance(pf_ch, pf_ty, pf_tx);
-        if constexpr (DEPTH > 1) {
-            issue(std::integral_constant<int, 1>{}, pf_ch, pf_ty, pf_tx);
-            if constexpr (DEEP_B) issueB(std::integral_constant<int, 1>{}, pf_ch);
-            advance(pf_ch, pf_ty, pf_tx);
-        }
     }
-    // GroupNorm's (scale, shift) table for this sample — after the first halo request is on its way; the statistics partials of a
-    // channel are fetched 16 at a time (one L2 round trip, not one per partial), the fp64 finalisation follows
-    if (has_gn) compute_gn_affine(a, n, emb_row, ab);
+    __builtin_amdgcn_sched_barrier(0);
+    CCDM_STAMP(13);
+    // the small loads issued at the top are consumed here, behind the first halo request
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const bool cv = tile_of(ni) * 32 + (lane & 31) < a.Cout;
+        float add = a.bias ? raw_bias[ni] : 0.f;
+        if (a.emb_off >= 0) add += raw_emb[ni];             // (conv + bias) + emb == conv + (bias + emb) up to 1 ulp
+        epi_add[ni] = (cv && krow == 0) ? add : 0.f;        // bias (+emb) enters once, through row group 0's partial
+        if (!cv) epi_wsc[ni] = 1.0f;
+    }
+    // GroupNorm's (scale, shift) table for this sample, from the prefetched partials (the halo region of LDS is free until the
+    // first commit, which sits behind the loop-top barrier)
+    if (has_gn) gn_affine_block(a, n, emb_row, gpf, reinterpret_cast<f64x2*>(halo_b), ab);
+    CCDM_STAMP(14);
     // one iteration = one (tile, chunk); D_ = the register set it consumes (static: the loop below is unrolled by DEPTH)
     auto iterate = [&](auto D_) {
         if (chunk == 0) {
@@ -1046,7 +1062,10 @@ int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
     if (lds < red) lds = red;
     const size_t epi = (size_t)g.waves * ksp * g.MI * 32 * 36 * 4;        // epilogue transpose buffer (wave-private rows)
     if (lds < epi) lds = epi;
-    if (a.stats0) lds += (size_t)C * 8;
+    if (a.stats0) {
+        if (lds < (size_t)C * 16) lds = (size_t)C * 16;       // the prologue's per-channel statistics exchange (gn_affine_block) aliases the tiles
+        lds += (size_t)C * 8;
+    }
     if ((a.prec >> 8) & 512) lds = 60 * 1024;      // diagnostics (tools/bench_conv.py): at most 2 blocks per CU
     if ((a.prec >> 8) & 1024) lds = 100 * 1024;    //                                   1 block per CU
     CCDM_REQUIRE(lds <= 160 * 1024, "conv: LDS %zu too large", lds);

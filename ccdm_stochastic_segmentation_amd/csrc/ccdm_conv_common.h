@@ -17,6 +17,14 @@ __device__ __forceinline__ f32x4 load16_uniform_base(const char* base, unsigned 
     return *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(g + voff);
 }
 
+// Load 16 bytes of GLOBAL memory through a pointer whose address space the compiler cannot see (rebuilt from integers / register
+// lanes).  Left generic it becomes flat_load, which also counts in LGKM_CNT: the wave's next LDS wait (s_waitcnt lgkmcnt) then waits
+// for this memory round trip too, and with a flat load pending the waitcnt pass can no longer count vector loads in order (vmcnt(N)
+// becomes vmcnt(0)).
+__device__ __forceinline__ f32x4 load16_global(const char* p) {
+    return *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(reinterpret_cast<unsigned long long>(p));
+}
+
 // NT: non-temporal (streaming) store — the line is marked evict-first in L2
 template <bool NT = false>
 __device__ __forceinline__ void store16_uniform_base(char* base, unsigned voff, const f32x4 v) {
@@ -120,6 +128,72 @@ __device__ __forceinline__ float2 gn_finalize(const ccdm_conv_args& a, const GnP
         sh = sh * one_plus + p.film_shift;
     }
     return make_float2(sc, sh);
+}
+
+// Prologue form for k_conv.  gn_prefetch issues EVERY load the affine of channel c needs — gamma, beta, the FiLM row and the
+// channel's own first 16 slice partials — unconditionally (addresses clamped; `dummy` = any readable device memory, read when there
+// is no GroupNorm), with two or three instructions of address arithmetic per load and no branch, and waits for none of them.  The
+// kernel then issues its first halo request; the small loads return first (vector memory returns in order), so gn_affine_block —
+// per-channel sums over the slices (ascending), exchanged through LDS, added over the group's channels (ascending), finalised in
+// fp64 — runs while the halo is in flight.  (A branch between the loads and their use would make the waitcnt pass drain the whole
+// queue at the join; a flat-addressed load anywhere in flight does the same.)
+struct GnPrefetch { GnParams p; f64x2 v[16]; };
+__device__ __forceinline__ const char* gn_channel_row(const ccdm_conv_args& a, int n, int c, int& S, unsigned& stride) {
+    const bool second = c >= a.C0;                                       // (only with a concatenated input)
+    const double* st = second ? a.stats1 : a.stats0;
+    const int ci = second ? c - a.C0 : c, Cs = second ? a.C1 : a.C0;
+    S = second ? a.slices1 : a.slices0;
+    stride = (unsigned)Cs * 16u;
+    return reinterpret_cast<const char*>(st + ((size_t)n * S * Cs + ci) * 2);
+}
+__device__ __forceinline__ void gn_prefetch(const ccdm_conv_args& a, bool has_gn, int n, int emb_row, int c, const void* dummy, GnPrefetch& g) {
+    const int C = a.C0 + a.C1;
+    const float* df = static_cast<const float*>(dummy);
+    const bool film = has_gn && a.film;
+    const float* gam = has_gn ? a.gamma + c : df;
+    const float* bet = has_gn ? a.beta + c : df;
+    const float* row = film ? a.emb_table + (size_t)emb_row * a.emb_stride + a.film_off + c : df;
+    g.p.gamma = *gam; g.p.beta = *bet;
+    g.p.film_scale = row[0]; g.p.film_shift = row[film ? C : 0];
+    int S = 1;
+    unsigned stride = 0;
+    const char* base = static_cast<const char*>(dummy);
+    if (has_gn) base = gn_channel_row(a, n, c, S, stride);               // uniform condition, selects only
+    const unsigned last = (unsigned)(S - 1) * stride;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) g.v[u] = *reinterpret_cast<const f64x2*>(base + min((unsigned)u * stride, last));
+}
+// this channel's (sum, sum^2) over its slices, ascending; g: the first 16 partials if they were prefetched, else NULL
+__device__ __forceinline__ f64x2 gn_channel_sums(const ccdm_conv_args& a, int n, int c, const GnPrefetch* g) {
+    int S;
+    unsigned stride;
+    const char* base = gn_channel_row(a, n, c, S, stride);
+    f64x2 acc = {0.0, 0.0};
+    int s0 = 0;
+    if (g) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {                                   // selects, not branches (x + 0.0 == x)
+            acc[0] += u < S ? g->v[u][0] : 0.0;
+            acc[1] += u < S ? g->v[u][1] : 0.0;
+        }
+        s0 = 16;
+    }
+    for (int s = s0; s < S; ++s) acc += *reinterpret_cast<const f64x2*>(base + (unsigned)s * stride);
+    return acc;
+}
+// the whole table ab[0..C): call with the block's threads converged; `scratch` = C x 16 B of LDS not otherwise in use until the
+// caller's next barrier
+__device__ __forceinline__ void gn_affine_block(const ccdm_conv_args& a, int n, int emb_row, const GnPrefetch& g, f64x2* scratch, float2* ab) {
+    const int C = a.C0 + a.C1, cpg = C / 32;
+    const int tid = threadIdx.x, NT = blockDim.x;
+    for (int c = tid; c < C; c += NT) scratch[c] = gn_channel_sums(a, n, c, c == tid ? &g : nullptr);
+    __syncthreads();
+    for (int c = tid; c < C; c += NT) {
+        const int c_lo = (c / cpg) * cpg;
+        f64x2 acc = {0.0, 0.0};
+        for (int j = 0; j < cpg; ++j) acc += scratch[c_lo + j];
+        ab[c] = gn_finalize(a, c == tid ? g.p : gn_params(a, emb_row, c), acc[0], acc[1]);
+    }
 }
 
 __device__ __forceinline__ void compute_gn_affine(const ccdm_conv_args& a, int n, int emb_row, float2* ab, int c_first = 0) {

@@ -177,7 +177,7 @@ __global__ __launch_bounds__((PC_NL + 4) * 64, 3) void k_conv_pc(const ConvK k) 
             const bool ok = cok & (e < (unsigned)EDGE_ITEMS) & ((unsigned)iy < (unsigned)Hc) & ((unsigned)ix < (unsigned)Wc);
             const int iyc = min(max(iy, ylo), yhi), ixc = min(max(ix, xlo), xhi);
             const unsigned sy = (unsigned)(iyc >> ups), sx = (unsigned)(ixc >> ups);
-            reg[d][NCORE + j] = *reinterpret_cast<const f32x4*>(srcb + (size_t)(sy * rowb + ((sx * (unsigned)Cs + cq) << 2)));
+            reg[d][NCORE + j] = load16_global(srcb + (size_t)(sy * rowb + ((sx * (unsigned)Cs + cq) << 2)));
             evalid[d] |= (ok ? 1u : 0u) << j;
         }
     };

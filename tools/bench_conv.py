@@ -83,7 +83,7 @@ def timeline(prec, shape):
     hip.check(lib.ccdm_debug_read_timeline(buf, 1024))
     n = int(buf[1023])
     ev = [(int(buf[i]) >> 56, int(buf[i]) & ((1 << 56) - 1)) for i in range(min(n, 1020))]
-    names = {1: "start", 2: "top(prev phase end)", 3: "barrierA", 4: "commit", 5: "barrierB", 6: "issue", 7: "mfma", 8: "end", 9: "epi-barrier", 10: "epi-transpose", 11: "epi-rows"}
+    names = {12: "kernel-entry", 1: "start", 2: "top(prev phase end)", 3: "barrierA", 4: "commit", 5: "barrierB", 6: "issue", 7: "mfma", 8: "end", 9: "epi-barrier", 10: "epi-transpose", 11: "epi-rows", 13: "first-issue", 14: "gn-affine"}
     t0 = ev[0][1]
     prev = t0
     out = []
