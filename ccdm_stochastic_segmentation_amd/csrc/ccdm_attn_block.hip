@@ -123,21 +123,33 @@ __global__ __launch_bounds__((T / 32) * 64) void k_qkv_attention(const AttnBlock
     wload(0);
     // ---- tables: GroupNorm affine from the producer's per-channel partial sums; this head's biases and weight un-scales ----
     {
+        // per-channel sums over the slices (16 independent loads, not one round trip per partial), exchanged through LDS (the K-row
+        // region is free until the qkv GEMM has finished), then added over the group's channels — all in ascending order
         constexpr int cpg = C / 32;
-        const double cnt = (double)cpg * (double)T;
+        f64x2* scratch = reinterpret_cast<f64x2*>(kbase);
+        const int S = a.slices;
+        for (int c = tid; c < C; c += NT) {
+            const char* base = reinterpret_cast<const char*>(a.stats + ((size_t)n * S * C + c) * 2);
+            const unsigned stride = (unsigned)C * 16u, last = (unsigned)(S - 1) * stride;
+            f64x2 v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const f64x2*>(base + min((unsigned)u * stride, last));
+            f64x2 own = {0.0, 0.0};
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { own[0] += u < S ? v[u][0] : 0.0; own[1] += u < S ? v[u][1] : 0.0; }
+            for (int s = 16; s < S; ++s) own += *reinterpret_cast<const f64x2*>(base + (unsigned)s * stride);
+            scratch[c] = own;
+        }
+        __syncthreads();
         for (int c = tid; c < C; c += NT) {
             const int c_lo = (c / cpg) * cpg;
-            double sum = 0.0, sq = 0.0;
-            for (int cc = c_lo; cc < c_lo + cpg; ++cc) {
-                const double* p = a.stats + ((size_t)n * a.slices * C + cc) * 2;
-                for (int s = 0; s < a.slices; ++s) { sum += p[(size_t)s * C * 2]; sq += p[(size_t)s * C * 2 + 1]; }
-            }
-            const double mean = sum / cnt;
-            double var = sq / cnt - mean * mean;
-            if (var < 0.0) var = 0.0;
-            const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+            f64x2 g = {0.0, 0.0};
+#pragma unroll
+            for (int j = 0; j < cpg; ++j) g += scratch[c_lo + j];
+            float meanf, rstd;
+            gn_mean_rstd(g[0], g[1], (double)cpg * (double)T, a.eps, meanf, rstd);
             const float sc = rstd * a.gamma[c];
-            const float sh = a.beta[c] - sc * (float)mean;
+            const float sh = a.beta[c] - sc * meanf;
             ab[c] = make_float2(sc * ACT_PRESCALE, sh * ACT_PRESCALE);       // activation pre-scale 2^4, undone through wsq
         }
         for (int i = tid; i < 96; i += NT) { tb[i] = a.bqkv[96 * hd + i]; tb[96 + i] = k.wsq[96 * hd + i]; }

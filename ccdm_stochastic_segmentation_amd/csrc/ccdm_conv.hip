@@ -222,6 +222,14 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
     constexpr bool DEEP_B = CCDM_DEEP_PREFETCH && PREC != CCDM_PREC_F32 && CKT == 32 && 8 * (NITEM + NITEM_B) <= 136;
     constexpr bool DEEP_A = CCDM_DEEP_HALO && PREC != CCDM_PREC_F32 && STRIDE == 1 && TW == 32 && NI == 1;
     constexpr int DEPTH = (DEEP_A || DEEP_B) ? 2 : 1;
+    // EARLY_B (experiment, off): narrow-tile variants request the NEXT chunk's weight fragments together with the next halo, right
+    // after the commit has emptied the fragment registers, instead of at the top of the iteration that consumes them.  The timeline
+    // shows 1700 cycles of barrier wait for them in the second chunk of an 8x8 block, yet the whole LIDC step measured 0.5-1 % SLOWER
+    // with it (same box, 3.209 -> 3.233 ms): like the two-deep prefetch above, not a win.
+#ifndef CCDM_EARLY_B
+#define CCDM_EARLY_B 0
+#endif
+    constexpr bool EARLY_B = CCDM_EARLY_B && !DEEP_B && PREC != CCDM_PREC_F32 && TW < 32;
     constexpr int DEPTH_B = DEEP_B ? 2 : 1;
     f32x4 reg[DEPTH][NITEM];
     f32x4 regB[DEPTH_B][NITEM_B > 0 ? NITEM_B : 1];
@@ -499,7 +507,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
     // prologue: fill every register set (sets beyond the last iteration request clamped addresses: harmless, branch-free)
     // (a launch always has n_iter >= 1: slices <= tiles)
     issue(std::integral_constant<int, 0>{}, pf_ch, pf_ty, pf_tx);
-    if constexpr (DEEP_B) issueB(std::integral_constant<int, 0>{}, pf_ch);
+    if constexpr (DEEP_B || EARLY_B) issueB(std::integral_constant<int, 0>{}, pf_ch);
     advance(pf_ch, pf_ty, pf_tx);
     if constexpr (DEPTH > 1) {
         issue(std::integral_constant<int, 1>{}, pf_ch, pf_ty, pf_tx);
@@ -532,7 +540,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                     for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
         }
         CCDM_STAMP(2);
-        if constexpr (!DEEP_B) { if (!CCDM_DBG(4)) issueB(D_, chunk); }
+        if constexpr (!DEEP_B && !EARLY_B) { if (!CCDM_DBG(4)) issueB(D_, chunk); }
         if (!CCDM_DBG(256)) __syncthreads();          // previous MFMA phase has finished reading LDS (and ab[] is visible)
         CCDM_STAMP(3);
         if (!CCDM_DBG(2)) commit(D_, chunk);
@@ -543,7 +551,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
         // slice's last one: addresses are clamped into the tensor, the data is never committed — harmless, branch-free)
         if (!CCDM_DBG(4)) {       // refill the set just committed: iteration it + DEPTH
             issue(D_, pf_ch, pf_ty, pf_tx);
-            if constexpr (DEEP_B) issueB(D_, pf_ch);
+            if constexpr (DEEP_B || EARLY_B) issueB(D_, pf_ch);
             advance(pf_ch, pf_ty, pf_tx);
         }
 

@@ -99,6 +99,25 @@ __device__ __forceinline__ void gn_group_sums(const ccdm_conv_args& a, int n, in
     }
 }
 
+// mean and 1/sqrt(var + eps) of a group from its (sum, sum^2) over cnt values.  fp64 throughout, but without the division /
+// square-root expansions (three v_div sequences and a v_sqrt: ~800 cycles of a block prologue that small-spatial launches cannot
+// hide): hardware reciprocal / reciprocal-square-root estimates refined by two Newton steps each — relative error < 2^-50,
+// invisible after the rounding to fp32.
+__device__ __forceinline__ void gn_mean_rstd(double sum, double sq, double cnt, float eps, float& meanf, float& rstd) {
+    double ic = __builtin_amdgcn_rcp(cnt);
+    ic = ic * (2.0 - cnt * ic);
+    ic = ic * (2.0 - cnt * ic);
+    const double mean = sum * ic;
+    double var = sq * ic - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double ve = var + (double)eps;
+    double rs = __builtin_amdgcn_rsq(ve);
+    rs = rs * (1.5 - 0.5 * ve * rs * rs);
+    rs = rs * (1.5 - 0.5 * ve * rs * rs);
+    meanf = (float)mean;
+    rstd = (float)rs;
+}
+
 // per-channel parameters of the affine, fetched ahead of the arithmetic (gn_params) so that a kernel can issue every small load
 // before its first HBM request and do the fp64 finalisation (gn_finalize: registers only) while that request is in flight
 struct GnParams { float gamma, beta, film_scale, film_shift; };
@@ -114,12 +133,8 @@ __device__ __forceinline__ GnParams gn_params(const ccdm_conv_args& a, int emb_r
 __device__ __forceinline__ float2 gn_finalize(const ccdm_conv_args& a, const GnParams& p, double sum, double sq) {
     const int C = a.C0 + a.C1;
     const int cpg = C / 32;
-    const double cnt = (double)cpg * (double)a.Hin * (double)a.Win;
-    const double mean = sum / cnt;
-    double var = sq / cnt - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
-    const float meanf = (float)mean;
+    float meanf, rstd;
+    gn_mean_rstd(sum, sq, (double)cpg * (double)a.Hin * (double)a.Win, a.eps, meanf, rstd);
     float sc = rstd * p.gamma;
     float sh = p.beta - sc * meanf;
     if (a.film) {   // h = GN(h) * (1 + scale) + shift          unet.py:254-258

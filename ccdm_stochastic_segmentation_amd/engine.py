@@ -18,6 +18,7 @@ import torch
 from . import hip
 from .unet_spec import GN_EPS, UNetSpec
 
+_TIMELINE_OP = int(os.environ.get("CCDM_TIMELINE_OP", "-1"))          # tools/timeline_op.py
 _NO_SUBPIXEL = bool(int(os.environ.get("CCDM_NO_SUBPIXEL", "0")))     # same-box A/B hook: Upsample convs in the direct (9-tap) form
 
 
@@ -172,6 +173,8 @@ class SamplerEngine:
             args.skip0, args.SC0 = sa.ptr, sa.C
             args.skip1, args.SC1 = (sb.ptr, sb.C) if sb else (0, 0)
             args.skip_w = skip_w.data_ptr()
+        if len(self.op_names) == _TIMELINE_OP:      # diagnostics: phase stamps of one block of this op (-DCCDM_ABLATION library only)
+            args.prec |= 16 << 8
         hip.check(self.lib.ccdm_engine_add_conv(self._handle, C.byref(args)), "engine_add_conv " + wkey)
         self.op_names.append(wkey)
         # algorithmic work of this launch per SAMPLE (SURVEY 8d accounting: conv io + one GroupNorm statistics read + weights;

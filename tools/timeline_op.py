@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Phase timeline (s_memtime stamps) of one mid-grid block of ONE conv op inside the real denoise step — cold weights, the
+producer's output fresh in cache — as opposed to tools/bench_conv.py's back-to-back launches of one layer.
+    CCDM_LIB=tools/ab/abl.so CCDM_TIMELINE_OP=33 python tools/timeline_op.py       (library built with CCDM_ABLATION=1)"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from ccdm_stochastic_segmentation_amd import hip
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+
+NAMES = {12: "kernel-entry", 1: "start", 2: "top", 3: "barrierA", 4: "commit", 5: "barrierB", 6: "issue", 7: "mfma", 8: "end",
+         9: "epi-barrier", 10: "epi-transpose", 11: "epi-rows", 13: "first-issue", 14: "gn-affine"}
+
+if __name__ == "__main__":
+    sys.argv = [sys.argv[0], "--steps", "1", "--warmup", "0", "--denoise-steps", "4", "--no-cpu-baseline", "--no-secondary"] + sys.argv[1:]
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        bench.main()
+    torch.cuda.synchronize()
+    lib = hip.load()
+    buf = (C.c_ulonglong * 1024)()
+    hip.check(lib.ccdm_debug_read_timeline(buf, 1024))
+    n = int(buf[1023])
+    ev = [(int(buf[i]) >> 56, int(buf[i]) & ((1 << 56) - 1)) for i in range(min(n, 1020))]
+    prev = ev[0][1]
+    out = []
+    for slot, t in ev[1:]:
+        out.append(f"{NAMES.get(slot, slot)}+{t - prev}")
+        prev = t
+    print(f"op {os.environ.get('CCDM_TIMELINE_OP')}: total {prev - ev[0][1]} cycles: " + " ".join(out[:80]))
