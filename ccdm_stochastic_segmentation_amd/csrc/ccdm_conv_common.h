@@ -201,13 +201,24 @@ __device__ __forceinline__ f64x2 gn_channel_sums(const ccdm_conv_args& a, int n,
 __device__ __forceinline__ void gn_affine_block(const ccdm_conv_args& a, int n, int emb_row, const GnPrefetch& g, f64x2* scratch, float2* ab) {
     const int C = a.C0 + a.C1, cpg = C / 32;
     const int tid = threadIdx.x, NT = blockDim.x;
-    for (int c = tid; c < C; c += NT) scratch[c] = gn_channel_sums(a, n, c, c == tid ? &g : nullptr);
-    __syncthreads();
-    for (int c = tid; c < C; c += NT) {
+    auto group = [&](const int c) {
         const int c_lo = (c / cpg) * cpg;
         f64x2 acc = {0.0, 0.0};
         for (int j = 0; j < cpg; ++j) acc += scratch[c_lo + j];
-        ab[c] = gn_finalize(a, c == tid ? g.p : gn_params(a, emb_row, c), acc[0], acc[1]);
+        return acc;
+    };
+    // channel tid works from the prefetched values alone — no load here, which would be younger than the caller's halo request and
+    // drag its round trip into this wait; channels beyond the block size (C > NT: rare) take blocking loads
+    if (tid < C) scratch[tid] = gn_channel_sums(a, n, tid, &g);
+    for (int c = tid + NT; c < C; c += NT) scratch[c] = gn_channel_sums(a, n, c, nullptr);
+    __syncthreads();
+    if (tid < C) {
+        const f64x2 acc = group(tid);
+        ab[tid] = gn_finalize(a, g.p, acc[0], acc[1]);
+    }
+    for (int c = tid + NT; c < C; c += NT) {
+        const f64x2 acc = group(c);
+        ab[c] = gn_finalize(a, gn_params(a, emb_row, c), acc[0], acc[1]);
     }
 }
 
