@@ -395,6 +395,8 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
         constexpr bool F16 = PREC != CCDM_PREC_F32;
         constexpr float PS = F16 ? ACT_PRESCALE : 1.0f;
         if (GN && !ACT && F16) { t0.x *= PS; t0.y *= PS; t1.x *= PS; t1.y *= PS; t2.x *= PS; t2.y *= PS; t3.x *= PS; t3.y *= PS; }
+        // (packed fp32 pairs — v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32 for the affine, the sigmoid's argument and denominator and
+        //  the final product, 6 instructions instead of 12 per item — were measured 0.7 % SLOWER on the whole step: kept scalar)
         auto act = [&](const float x) {
             if (!ACT) return (GN || !F16) ? x : x * PS;
             // x * sigmoid(x) * PS with v_exp_f32 / v_rcp_f32 (1 ulp each); limits: x -> -inf gives -0, x -> +inf gives PS*x
