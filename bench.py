@@ -127,6 +127,8 @@ def main():
                          "on the host in the reference's order and copied over PCIe (host-RNG bound; reported for DESIGN.md, never the headline)")
     ap.add_argument("--prec", choices=["f32", "f16x3"], default="f16x3",
                     help="conv arithmetic: exact fp32 MFMA, or fp16 hi/lo split x3 MFMA with fp32 accumulate (~2^-22)")
+    ap.add_argument("--slicing", default="throughput", choices=["throughput", "latency"],
+                    help="DenoisingModel.slicing: 'latency' = more, shorter conv workgroups per sample (small batches)")
     ap.add_argument("--per-op", default="", help="write the per-op table of one extra tapped pass to this file (JSON)")
     args = ap.parse_args()
 
@@ -157,6 +159,7 @@ def main():
     model.rng, model.philox_seed, model.use_graph = args.rng, 2024, bool(args.graph)
     model.sample_offset = rank * n                                # Philox counters keyed by global sample index
     model.substreams = args.substreams
+    model.slicing = args.slicing
 
     rng = np.random.default_rng(1234)
     if cfg["image"] == "uniform":
@@ -240,7 +243,8 @@ def main():
             "config": {"workload": f"{cfg['title']}, batch={n} per GPU, "
                                    f"{'device Philox RNG' if args.rng == 'philox' else 'host torch-CPU Exp(1) noise over PCIe (parity mode)'}, random-init weights",
                        "name": args.config, "global_batch": n * world, "time_steps": T, "denoise_steps_run": n_dsteps,
-                       "parallelism": f"batch-shard x{world}", "launch": "hip-graph" if args.graph else "eager", "substreams": nsub},
+                       "parallelism": f"batch-shard x{world}", "launch": "hip-graph" if args.graph else "eager", "substreams": nsub,
+                       "slicing": args.slicing},
         }
         step_bytes = (cfg["algo_mb"] * n + cfg["weights_mb"]) * 1e6
         fr = step_bytes / (ms_dstep * 1e-3) / 1e9

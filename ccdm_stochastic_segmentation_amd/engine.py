@@ -59,8 +59,9 @@ class SamplerEngine:
 
     def __init__(self, spec: UNetSpec, state_dict: Dict[str, torch.Tensor], N: int, H: int, W: int,
                  num_classes: int, img_channels: int, device: torch.device, max_steps: int,
-                 feature_shape: Optional[Tuple[int, int, int]] = None, prec: int = hip.PREC_F32):
+                 feature_shape: Optional[Tuple[int, int, int]] = None, prec: int = hip.PREC_F32, fine_slices: bool = False):
         self.lib = hip.load()
+        self.fine_slices = bool(fine_slices)       # latency slicing (ccdm_conv_args.fine_slices): more, shorter workgroups per sample
         if device.type != "cuda":
             raise hip.CcdmHipError("SamplerEngine needs a HIP device (torch device 'cuda'); there is no CPU path")
         self.spec, self.N, self.H, self.W = spec, int(N), int(H), int(W)
@@ -92,11 +93,11 @@ class SamplerEngine:
         self._keep.append(d)
         return d
 
-    def _act(self, C_: int, h: int, w: int, stats: bool, stride: int = 1, subpixel: bool = False) -> DevTensor:
+    def _act(self, C_: int, h: int, w: int, stats: bool, slices: int = 0) -> DevTensor:
         buf = self._dev((self.N, h, w, C_))
         t = DevTensor(buf, C_, h, w)
         if stats:
-            t.slices = self.lib.ccdm_upconv_slices(h // 2, w // 2) if subpixel else self.lib.ccdm_conv_slices(h, w, stride, 3)
+            t.slices = slices
             t.stats = self._dev((self.N, t.slices, C_, 2), torch.float64)
         return t
 
@@ -144,7 +145,8 @@ class SamplerEngine:
         pad = ksize // 2
         hout = (hc + 2 * pad - ksize) // stride + 1
         wout = (wc + 2 * pad - ksize) // stride + 1
-        out = self._act(cout, hout, wout, stats, stride, subpixel)
+        up_mode = 2 if subpixel else int(bool(up))
+        out = self._act(cout, hout, wout, stats, self.lib.ccdm_conv_slices_ex(hin, win, ksize, stride, up_mode, int(self.fine_slices)))
         args = hip.ConvArgs()
         args.in0, args.C0 = a.ptr, a.C
         args.in1, args.C1 = (b.ptr, b.C) if b else (0, 0)
@@ -157,7 +159,7 @@ class SamplerEngine:
         args.eps, args.act = GN_EPS, act
         args.film, args.film_off = (1, film_off) if film_off >= 0 else (0, 0)
         args.N, args.Hin, args.Win, args.Hout, args.Wout = self.N, hin, win, hout, wout
-        args.ksize, args.stride, args.up = ksize, stride, (2 if subpixel else int(up))
+        args.ksize, args.stride, args.up, args.fine_slices = ksize, stride, up_mode, int(self.fine_slices)
         args.w, args.bias, args.Cout, args.prec = wdev.data_ptr(), bias.data_ptr(), cout, self.prec
         args.emb_table, args.emb_stride, args.emb_off = self.emb_table.data_ptr(), self.E, emb_off
         args.emb_row_of_sample = self.rowmap.data_ptr()

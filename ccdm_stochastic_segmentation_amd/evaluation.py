@@ -132,7 +132,7 @@ def apply_sampler_options(model, params: dict) -> None:
     """Build-owned keys of the params file (absent in the reference's YAML, so an unchanged file runs the defaults):
          rng:  "philox" (default, device RNG) | "torch_cpu" (host generator in the reference's consumption order, parity mode)
          prec: "f16x3" (default) | "f32" (exact-fp32 kernels)
-         philox_seed, use_graph, substreams, on_range_error: DenoisingModel attributes of the same names."""
+         philox_seed, use_graph, substreams, on_range_error, slicing: DenoisingModel attributes of the same names."""
     from . import hip
     model.rng = str(params.get("rng", "philox"))
     prec = str(params.get("prec", "f16x3")).lower()
@@ -143,6 +143,8 @@ def apply_sampler_options(model, params: dict) -> None:
     model.use_graph = bool(params.get("use_graph", False))
     model.substreams = int(params.get("substreams", 1))          # 0 = automatic (DenoisingModel)
     model.on_range_error = str(params.get("on_range_error", "f32"))
+    model.slicing = str(params.get("slicing", "throughput"))
+    model._fine_slices(1)                                         # validates the value
 
 
 def _as_list(v) -> List[int]:

@@ -26,7 +26,7 @@ PREC_F32, PREC_F16X3 = 0, 1
 STEP_SAMPLE, STEP_LAST_CONFIDENCE, STEP_LAST_MAJORITY, STEP_LAST_KEEP, STEP_SOFTMAX_ONLY = 0, 1, 2, 3, 4
 STATS_MAX_SLICES = 32       # CCDM_STATS_MAX_SLICES: what a GroupNorm consumer reads
 STATS_FOLD_SLICES = 16      # CCDM_STATS_FOLD_SLICES: what the engine folds a larger slice count to
-ABI_VERSION = 3          # CCDM_ABI_VERSION of include/ccdm_hip.h
+ABI_VERSION = 4          # CCDM_ABI_VERSION of include/ccdm_hip.h
 
 
 class ConvArgs(C.Structure):
@@ -47,6 +47,7 @@ class ConvArgs(C.Structure):
         ("out_stats", C.c_void_p), ("out_slices", C.c_int32),
         ("skip0", C.c_void_p), ("skip1", C.c_void_p), ("SC0", C.c_int32), ("SC1", C.c_int32),
         ("skip_w", C.c_void_p),
+        ("fine_slices", C.c_int32),
     ]
 
 
@@ -85,6 +86,7 @@ SIGNATURES = {
     "ccdm_last_error_string": (C.c_char_p, []),
     "ccdm_gn_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ccdm_conv_slices": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ccdm_conv_slices_ex": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ccdm_upconv_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "ccdm_upconv_slices": (C.c_int, [C.c_int, C.c_int]),
     "ccdm_pack_upconv_weight": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),

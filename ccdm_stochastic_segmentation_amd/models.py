@@ -287,11 +287,22 @@ class DenoisingModel(nn.Module):
         # exact-fp32 kernels (same seeds, so the samples are the ones an all-fp32 run would have drawn) and log a warning;
         # "raise" = propagate the error
         self.on_range_error = "f32"
+        # workgroup slicing of the conv kernels: "throughput" (default) = the batch-size-independent rule — samples do not depend on how
+        # a batch is sharded over ranks or sub-batches, bit for bit; "latency" = up to 32 one- or two-tile workgroups per sample
+        # (ccdm_conv_args.fine_slices) for batches too small to fill the chip (LIDC batch 8: 2.06 -> 1.73 ms per denoise step; batch
+        # 64 loses 5 %): GroupNorm's partial sums are then added in another order, so its samples may differ from the default mode's in
+        # the last bit of a probability (never between two runs of the same mode and batch split)
+        self.slicing = "throughput"
         self._engines: Dict[Any, Tuple[int, SamplerEngine]] = {}
 
     @property
     def time_steps(self) -> int:
         return self.diffusion.time_steps
+
+    def _fine_slices(self, N: int) -> bool:
+        if self.slicing not in ("throughput", "latency"):
+            raise ValueError(f"slicing: {self.slicing!r} (expected 'throughput' or 'latency')")
+        return self.slicing == "latency"
 
     # ------------------------------------------------------------------ reference API
     def forward(self, x: Tensor, condition: Tensor, feature_condition: Tensor = None, t: Optional[Tensor] = None,
@@ -326,13 +337,13 @@ class DenoisingModel(nn.Module):
         if not spec.feature_condition_idx:
             fshape = None                        # no injection point configured: the reference ignores the tensor too
         dev = next(self.unet.parameters()).device
-        key = (N, H, W, int(condition.shape[1]), fshape, str(dev), self.prec, slot)
+        key = (N, H, W, int(condition.shape[1]), fshape, str(dev), self.prec, slot, self._fine_slices(N))
         wkey = self._weights_key()
         hit = self._engines.get(key)
         if hit is not None and hit[0] == wkey:
             return hit[1]
         eng = SamplerEngine(spec, self.unet.state_dict(), N, H, W, K, int(condition.shape[1]), dev,
-                            max_steps=self.time_steps, feature_shape=fshape, prec=self.prec)
+                            max_steps=self.time_steps, feature_shape=fshape, prec=self.prec, fine_slices=self._fine_slices(N))
         self._engines = {k: v for k, v in self._engines.items() if v[0] == wkey}
         self._engines[key] = (wkey, eng)
         return eng

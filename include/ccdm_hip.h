@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define CCDM_ABI_VERSION 3
+#define CCDM_ABI_VERSION 4
 #define CCDM_MAX_CHANNELS 1024      /* max C0+C1 of a GroupNorm'ed conv input */
 #define CCDM_STATS_MAX_SLICES 32    /* partial-statistics slices per sample a GroupNorm consumer reads (more: ccdm_stats_fold) */
 #define CCDM_STATS_FOLD_SLICES 16   /* what ccdm_stats_fold reduces a larger slice count to */
@@ -86,6 +86,11 @@ typedef struct ccdm_conv_args {
      * Requires stride 1, up 0, skip tensors [N,Hout,Wout,SC*].  skip0 == NULL: none. */
     const float* skip0; const float* skip1; int32_t SC0; int32_t SC1;
     const void* skip_w;
+    /* 1: latency slicing — more, shorter workgroups per sample (ccdm_conv_slices_ex(..., fine = 1): up to 32 slices where the
+     * default rule gives fewer, e.g. 32 instead of 12 at 128x128) for batches too small to fill the chip with the default.  The
+     * statistics partials — and with them the last bit of a GroupNorm — depend on the slice count, so a run is bit-reproducible
+     * across batch shardings only within one slicing mode; 0 (default) is the batch-size-independent rule. */
+    int32_t fine_slices;
 } ccdm_conv_args;
 
 /* number of statistics slices the conv kernel produces for an Hout x Wout output (depends only on the
@@ -93,6 +98,8 @@ typedef struct ccdm_conv_args {
  * CCDM_STATS_MAX_SLICES (one slice = one workgroup per sample: 256x512 -> 96, 512x1024 -> 384): fold them with
  * ccdm_stats_fold before handing them to a GroupNorm consumer. */
 int ccdm_conv_slices(int Hout, int Wout, int stride, int ksize);
+/* out_slices of any conv: geometry of the INPUT, `up` as in ccdm_conv_args (2: sub-pixel form), fine as ccdm_conv_args.fine_slices */
+int ccdm_conv_slices_ex(int Hin, int Win, int ksize, int stride, int up, int fine);
 /* Upsample (nearest x2) + conv 3x3 in sub-pixel form (unet.py:106-116), `up = 2`:
  *   out(2y+dy, 2x+dx) = sum over a,b in {0,1} of W'[dy,dx][a,b] . in(y+dy-1+a, x+dx-1+b),
  *   W'[dy][..][a] = the 3x3 kernel rows that land on low-resolution row y+dy-1+a  (dy=0: {r0}, {r1+r2}; dy=1: {r0+r1}, {r2}; columns alike):

@@ -30,7 +30,7 @@ def gn_stats(x_nhwc: torch.Tensor, slices: int = 1) -> torch.Tensor:
 
 
 def conv2d(srcs, weight, bias, ksize, *, stats=None, gamma=None, beta=None, act=hip.ACT_NONE, stride=1, up=False,
-           emb=None, emb_rows=None, film=None, resid=None, want_stats=True, prec=hip.PREC_F32, skip=None, bench=None):
+           emb=None, emb_rows=None, film=None, resid=None, want_stats=True, prec=hip.PREC_F32, skip=None, bench=None, fine=False):
     """srcs: list of 1-2 NHWC cuda tensors; weight OIHW numpy/torch cpu; stats: list of stats tensors or None.
     emb: [rows, E] cpu tensor added per output channel (row per sample via emb_rows) ; film: (table cpu [rows, 2C]).
     Returns (out NHWC cuda, out_stats or None)."""
@@ -70,7 +70,7 @@ def conv2d(srcs, weight, bias, ksize, *, stats=None, gamma=None, beta=None, act=
         args.gamma, args.beta = g.data_ptr(), bt.data_ptr()
     args.eps, args.act = 1e-5, act
     args.N, args.Hin, args.Win, args.Hout, args.Wout = N, Hin, Win, Hout, Wout
-    args.ksize, args.stride, args.up = ksize, stride, int(up)
+    args.ksize, args.stride, args.up, args.fine_slices = ksize, stride, int(up), int(fine)
     args.w, args.bias, args.Cout, args.prec = wdev.data_ptr(), bdev.data_ptr(), cout, prec
     args.emb_off = -1
     table = emb if emb is not None else film
@@ -96,7 +96,9 @@ def conv2d(srcs, weight, bias, ksize, *, stats=None, gamma=None, beta=None, act=
     args.out = out.data_ptr()
     ost = None
     if want_stats:
-        S = lib.ccdm_upconv_slices(Hin, Win) if up == 2 else lib.ccdm_conv_slices(Hout, Wout, stride, ksize)
+        S = lib.ccdm_conv_slices_ex(Hin, Win, ksize, stride, int(up), int(fine))
+        if not fine:
+            assert S == (lib.ccdm_upconv_slices(Hin, Win) if up == 2 else lib.ccdm_conv_slices(Hout, Wout, stride, ksize))
         ost = torch.empty((N, S, cout, 2), dtype=torch.float64, device=DEV)
         args.out_stats, args.out_slices = ost.data_ptr(), S
     hip.check(lib.ccdm_conv2d(C.byref(args), 0), "conv2d")

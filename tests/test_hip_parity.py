@@ -153,6 +153,37 @@ def test_upsample_conv_subpixel_form(U, cin, cout, H, W):
     np.testing.assert_allclose(st[..., 1].numpy(), (gd * gd).sum((2, 3)).numpy(), rtol=2e-6, atol=0)
 
 
+@pytest.mark.parametrize("c0,cout,H,W,k,stride,up", [(32, 32, 128, 128, 3, 1, 0), (64, 32, 64, 64, 3, 1, 0), (32, 32, 128, 128, 3, 2, 0),
+                                                     (32, 32, 64, 64, 3, 1, 2), (32, 32, 72, 40, 3, 1, 0), (96, 96, 16, 16, 1, 1, 0)])
+def test_conv_latency_slicing(U, c0, cout, H, W, k, stride, up):
+    """ccdm_conv_args.fine_slices: more, shorter workgroups per sample.  The conv output does not depend on the slicing (bit for bit);
+    the statistics come out as more partials whose sum is that of the default slicing up to fp64 rounding; a GroupNorm consumer reading
+    32 partials per channel gives the result it gives on the default 12."""
+    rng = np.random.default_rng(c0 + H + k + stride + up)
+    N = 2
+    x = rnd(rng, N, c0, H, W) * 1.3 + 0.2
+    w = rnd(rng, cout, c0, k, k) / np.sqrt(c0 * k * k)
+    b = rnd(rng, cout, scale=0.1)
+    xs = U.nhwc(x)
+    lib = hip.load()
+    base, st0 = U.conv2d([xs], w.numpy(), b.numpy(), k, stride=stride, up=up, prec=hip.PREC_F16X3)
+    fine, st1 = U.conv2d([xs], w.numpy(), b.numpy(), k, stride=stride, up=up, prec=hip.PREC_F16X3, fine=True)
+    assert torch.equal(base, fine)
+    assert st1.shape[1] >= st0.shape[1] and st1.shape[1] <= hip.STATS_MAX_SLICES
+    if (H, W, stride, up) == (128, 128, 1, 0):
+        assert (st0.shape[1], st1.shape[1]) == (12, 32)
+    np.testing.assert_allclose(st1.sum(1).cpu().numpy(), st0.sum(1).cpu().numpy(), rtol=1e-6, atol=1e-3)   # (per-lane fp32 partials regroup)
+    if cout % 32 == 0 and base.shape[1] >= 8:
+        # the next GroupNorm'ed conv on either statistics layout
+        g, be = 1 + rnd(rng, cout, scale=0.1), rnd(rng, cout, scale=0.1)
+        w2 = rnd(rng, 32, cout, 3, 3) / np.sqrt(cout * 9)
+        y0, _ = U.conv2d([base], w2.numpy(), np.zeros(32, np.float32), 3, stats=[st0], gamma=g.numpy(), beta=be.numpy(), act=hip.ACT_SILU,
+                         prec=hip.PREC_F16X3)
+        y1, _ = U.conv2d([fine], w2.numpy(), np.zeros(32, np.float32), 3, stats=[st1], gamma=g.numpy(), beta=be.numpy(), act=hip.ACT_SILU,
+                         prec=hip.PREC_F16X3, fine=True)
+        np.testing.assert_allclose(y1.cpu().numpy(), y0.cpu().numpy(), rtol=0, atol=2e-6)
+
+
 def test_upsample_conv_subpixel_form_refusals(U):
     lib = hip.load()
     assert lib.ccdm_upconv_supported(64, 64, hip.PREC_F16X3) == 1
@@ -826,6 +857,38 @@ def test_substreams_do_not_change_the_samples(U, rng_mode):
         torch.manual_seed(11)
         outs.append(model(x, img)["diffusion_out"].cpu())
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.gpu
+def test_latency_slicing_mode_of_the_model(U, parity_log):
+    """DenoisingModel.slicing = "latency" (more conv workgroups per sample, GroupNorm partials added in another order): the final
+    probabilities agree with the default mode to fp32 rounding over a teacher-free 6-step run, the mode is deterministic, and an
+    unknown value is refused."""
+    from ccdm_stochastic_segmentation_amd.models import build_model
+    from ccdm_stochastic_segmentation_amd.unet_spec import make_synthetic_state_dict
+    bp = dict(base_channels=32, channel_mult=(1, 1, 2), attention_resolutions=[4], num_heads=1, num_head_channels=32, softmax_output=True)
+    T, K, H, W, N = 6, 2, 128, 128, 3
+    model = build_model(T, "cosine", {"s": 0.008}, [(1, H, W), (K, H, W)], (1, H, W), "unet_openai", bp, "datasets.lidc", "confidence", None)
+    model.unet.load_state_dict({k: torch.from_numpy(v) for k, v in make_synthetic_state_dict(model.unet.spec, 4).items()}, strict=True)
+    model = model.to(U.DEV).eval()
+    model.prec, model.rng, model.philox_seed = hip.PREC_F16X3, "philox", 5
+    g = np.random.default_rng(6)
+    img = torch.from_numpy(g.uniform(-1, 1, (N, 1, H, W)).astype(np.float32)).to(U.DEV)
+    x = torch.nn.functional.one_hot(torch.from_numpy(g.integers(0, K, (N, H, W))), K).permute(0, 3, 1, 2).float().to(U.DEV)
+    outs = {}
+    for mode in ("throughput", "latency", "latency"):
+        model.slicing = mode
+        outs.setdefault(mode, []).append(model(x, img)["diffusion_out"].cpu())
+    assert torch.equal(outs["latency"][0], outs["latency"][1])
+    d = (outs["latency"][0] - outs["throughput"][0]).abs()
+    # a flipped draw (probability difference of one ulp straddling the sampled uniform) would show as a pixel-sized difference
+    frac_big = float((d > 1e-3).float().mean())
+    parity_log("latency_slicing_vs_default", max_abs=float(d.max()), frac_gt_1e3=frac_big)
+    assert float(d.median()) <= 1e-6 and frac_big <= 1e-3
+    model.slicing = "fast"
+    with pytest.raises(ValueError, match="slicing"):
+        model(x, img)
+    model.slicing = "throughput"
 
 
 # ------------------------------------------------------------------------------------------ training-time forward pieces (N3)

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(hip.SIGNATURES), declared ^ set(hip.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ccdm_version() == hip.ABI_VERSION == 3
+    assert lib.ccdm_version() == hip.ABI_VERSION == 4
     assert ctypes.sizeof(hip.ConvArgs) % 8 == 0 and ctypes.sizeof(hip.PostArgs) % 8 == 0
 
 
@@ -78,6 +78,13 @@ def test_pack_conv_weight_layout():
     assert hip.load().ccdm_conv_slices(128, 128, 1, 3) == 12
     assert hip.load().ccdm_conv_slices(16, 16, 1, 3) == 2
     assert hip.load().ccdm_conv_slices(8, 8, 1, 3) == 1
+    lib = hip.load()
+    # ccdm_conv_slices_ex: from the INPUT geometry; fine = the latency slicing (up to 32 slices where the default gives fewer)
+    assert lib.ccdm_conv_slices_ex(128, 128, 3, 1, 0, 0) == 12 and lib.ccdm_conv_slices_ex(128, 128, 3, 1, 0, 1) == 32
+    assert lib.ccdm_conv_slices_ex(128, 128, 3, 2, 0, 0) == lib.ccdm_conv_slices(64, 64, 2, 3)
+    assert lib.ccdm_conv_slices_ex(64, 64, 3, 1, 0, 1) == 16 and lib.ccdm_conv_slices_ex(8, 8, 3, 1, 0, 1) == 1
+    assert lib.ccdm_conv_slices_ex(64, 64, 3, 1, 2, 0) == lib.ccdm_upconv_slices(64, 64) == 8 and lib.ccdm_conv_slices_ex(64, 64, 3, 1, 2, 1) == 32
+    assert lib.ccdm_conv_slices_ex(256, 512, 3, 1, 0, 1) == lib.ccdm_conv_slices(256, 512, 1, 3) == 96
 
 
 def test_pack_upconv_weight_is_the_phase_summed_2x2_kernel():
@@ -358,8 +365,8 @@ def test_sampler_options_from_params_file():
     assert m.prec == hip.PREC_F16X3 and m.rng == "philox"            # the defaults ARE the benchmarked configuration
     E.apply_sampler_options(m, {})
     assert m.prec == hip.PREC_F16X3 and m.rng == "philox" and m.on_range_error == "f32"
-    E.apply_sampler_options(m, {"prec": "f32", "rng": "torch_cpu", "philox_seed": 9, "substreams": 2})
-    assert m.prec == hip.PREC_F32 and m.rng == "torch_cpu" and m.philox_seed == 9 and m.substreams == 2
+    E.apply_sampler_options(m, {"prec": "f32", "rng": "torch_cpu", "philox_seed": 9, "substreams": 2, "slicing": "latency"})
+    assert m.prec == hip.PREC_F32 and m.rng == "torch_cpu" and m.philox_seed == 9 and m.substreams == 2 and m.slicing == "latency"
     with pytest.raises(ValueError, match="prec"):
         E.apply_sampler_options(m, {"prec": "bf16"})
 

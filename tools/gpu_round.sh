@@ -17,9 +17,10 @@ timeout 900 python bench.py --config c4 --steps 2 --warmup 1 --per-op gpurun_out
 timeout 900 python bench.py --config c4b64 --steps 1 --warmup 1 --no-secondary > gpurun_out/bench_c4b64_$TAG.json 2> gpurun_out/bench_c4b64_$TAG.err
 timeout 1200 python bench.py --config c5shard --steps 1 --warmup 1 --per-op gpurun_out/per_op_c5_$TAG.json > gpurun_out/bench_c5shard_$TAG.json 2> gpurun_out/bench_c5shard_$TAG.err
 timeout 900 python bench.py --batch 8 --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > gpurun_out/bench_b8_$TAG.json 2> gpurun_out/bench_b8_$TAG.err
+timeout 900 python bench.py --batch 8 --slicing latency --steps 3 --warmup 1 --no-cpu-baseline --no-secondary > gpurun_out/bench_b8lat_$TAG.json 2> gpurun_out/bench_b8lat_$TAG.err
 fi
 cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$TAG -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary > $GRAFT_REPO_ROOT/gpurun_out/rocprof_$TAG.log 2>&1
 cd $GRAFT_REPO_ROOT
 find gpurun_out/prof_$TAG -name "*kernel_stats*" | head; ls -la gpurun_out/prof_$TAG | head
 tail -8 gpurun_out/pytest_gpu_$TAG.log; cat gpurun_out/smoke_$TAG.log | tail -3
-for f in eager graph f32 c4 c4b64 c5shard b8; do echo "== $f"; cat gpurun_out/bench_${f}_$TAG.json 2>/dev/null | cut -c1-1800; tail -2 gpurun_out/bench_${f}_$TAG.err 2>/dev/null; done
+for f in eager graph f32 c4 c4b64 c5shard b8 b8lat; do echo "== $f"; cat gpurun_out/bench_${f}_$TAG.json 2>/dev/null | cut -c1-1800; tail -2 gpurun_out/bench_${f}_$TAG.err 2>/dev/null; done

@@ -12,6 +12,7 @@ cpif $G/bench_c4_$TAG.json $P/${R}_bench_c4.json
 cpif $G/bench_c4b64_$TAG.json $P/${R}_bench_c4b64.json
 cpif $G/bench_c5shard_$TAG.json $P/${R}_bench_c5shard.json
 cpif $G/bench_b8_$TAG.json $P/${R}_bench_batch8.json
+cpif $G/bench_b8lat_$TAG.json $P/${R}_bench_batch8_latency_slicing.json
 cpif $G/per_op_$TAG.json $P/${R}_per_op_c2.json
 cpif $G/per_op_c4_$TAG.json $P/${R}_per_op_c4.json
 cpif $G/per_op_c5_$TAG.json $P/${R}_per_op_c5shard.json
