@@ -189,11 +189,13 @@ def main():
     n_tap = n // nsub
     eng = model._engine(x[:n_tap], image[:n_tap], feat[:n_tap] if feat is not None else None, slot=0)
     # The dominant kernel = the conv instantiation of the full-resolution stage: every 3x3 stride-1 conv whose output is HxW runs
-    # the same k_conv<...> symbol on the same grid (C2: 13 launches per denoise step, 42 % of its time) — the unit rocprofv3's
+    # the same k_conv<...> symbol on the same grid (C2: 12 launches per denoise step, 41 % of its time) — the unit rocprofv3's
     # per-kernel statistics report.  All of its launches are tapped; `roofline` is their aggregate (sum of algorithmic bytes
     # over sum of durations), `roofline_shapes` splits it by layer shape.
     info = eng.op_info
-    dom_ops = [i for i, o in enumerate(info) if o["kind"] == "conv" and o["k"] == 3 and o["stride"] == 1 and (o["hout"], o["wout"]) == (H, W)]
+    # (the Upsample conv that lands on HxW runs the sub-pixel instantiation k_conv<...,UP2> on the low-resolution grid: another symbol)
+    dom_ops = [i for i, o in enumerate(info) if o["kind"] == "conv" and o["k"] == 3 and o["stride"] == 1 and (o["hout"], o["wout"]) == (H, W)
+               and not o.get("subpixel")]
     attn_ops = [i for i, o in enumerate(info) if o["kind"] == "attention" and o["T"] >= 2048]
     attn = max(attn_ops, key=lambda i: info[i]["T"]) if attn_ops else None
     taps = not args.graph

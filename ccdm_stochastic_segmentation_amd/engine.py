@@ -190,7 +190,7 @@ class SamplerEngine:
             flop += 2 * sc * cout * hout * wout
             wbytes += 4 * cout * sc
         self.op_info.append(dict(kind="conv", name=wkey, cin=cin, cout=cout, k=ksize, hin=hin, win=win, hout=hout, wout=wout,
-                                 stride=stride, up=bool(up), gn=gn is not None, skip=skip_src is not None,
+                                 stride=stride, up=bool(up), subpixel=subpixel, gn=gn is not None, skip=skip_src is not None,
                                  io_bytes=io, gn_read_bytes=(4 * cin * hin * win if gn is not None else 0), weight_bytes=wbytes, flop=flop))
         self._fold_stats(out)
         return out
