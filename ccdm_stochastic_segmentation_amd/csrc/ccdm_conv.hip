@@ -1062,6 +1062,12 @@ int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
                                               (up2 ? packed_frag_bytes(4 * a.Cout, C, 2, prec) : packed_frag_bytes(a.Cout, C, a.ksize, prec)));
     const int want_slices = (up2 && NI == 1 ? 4 : 1) * k.slices;      // one phase per block: every (slice, phase) pair leaves a partial
     if (a.out_stats) CCDM_REQUIRE(a.out_slices == want_slices, "conv: out_slices %d != %d", a.out_slices, want_slices);
+    if (conv1x1_eligible(a, k.slices)) {           // AttentionBlock.proj_out + residual at the low-resolution stages: no LDS staging at all
+        const int rc1 = launch_conv1x1(a, k.slices, k.ntiles, k.wscale, s);
+        if (rc1) return rc1;
+        CCDM_CHECK_LAUNCH("conv1x1");
+        return 0;
+    }
     const int HP = ((g.TH - 1) * a.stride + a.ksize) * ((g.TW - 1) * a.stride + a.ksize);
     const int ck = chunk_ck(a, g);
     {   // core halo items need no per-lane padding mask when every tile column and every channel quad exists (see ConvK)

@@ -1,0 +1,144 @@
+// Plain 1x1 conv (+bias +residual, + per-channel output statistics) of a low-resolution tensor, F16X3 arithmetic:
+// AttentionBlock.proj_out + the block's residual (reference unet.py:300,311) — 11 launches per LIDC denoise step.
+//
+// The general kernel (ccdm_conv.hip) stages every input through LDS — two barrier-separated round trips per channel chunk,
+// a halo walk, a commit pass — which is what a 3x3 conv with GroupNorm on load needs and what a 64-pixel x 128-channel GEMM
+// does not: such a launch is one round of blocks and its time is one block's chain (tools/timeline_op.py: 14 000 cycles, of
+// which the arithmetic is under 2 000).  Here a wave's A operand never touches LDS: lane (pixel = lane & 31, k-group = lane >> 5)
+// reads its 8 consecutive channels of every 16-channel k-step straight into registers (2 x 16 B), splits them (x = hi + lo) and
+// feeds the MFMA; the B fragments are read in their packed layout (ccdm_pack_conv_weight: [k-step][n-tile][hi|lo][lane] x 16 B,
+// one coalesced 1 KB request per fragment).  Every load of the block — A, B, residual, bias, weight scales — is issued before the
+// first use: ONE memory round trip, no barrier before the statistics fold.
+//
+//   block = one statistics slice of one sample (HW / slices pixels, 32 per wave) x one 32-channel output tile
+//   same products in the same order as ccdm_conv.hip's 1x1 path (k-steps ascending; lo*hi, hi*lo, hi*hi): identical outputs.
+//   statistics: lane = channel, 16 pixels per lane in fp32, widened to fp64 before lanes and waves are combined (fixed order).
+#include "ccdm_common.h"
+#include "ccdm_conv_common.h"
+
+#include <cstdlib>
+
+namespace ccdm {
+
+struct Conv1x1K {
+    const float* in;        // [N, HW, C]
+    const void* w;          // packed fragments, ksize 1
+    const float* wscale;    // [ntiles*32]
+    const float* bias;      // [Cout] or NULL
+    const float* resid;     // [N, HW, Cout] or NULL
+    float* out;             // [N, HW, Cout]
+    double* out_stats;      // [N, slices, Cout, 2] or NULL
+    int C, Cout, HW, slices, ntiles, px_per_block;
+};
+
+// KSB k-steps (16 channels each) are in flight at a time: C <= 16 * KSB runs with every load issued up front
+template <int KSB>
+__global__ __launch_bounds__(256) void k_conv1x1(const Conv1x1K k) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const int n = blockIdx.x / k.slices, slice = blockIdx.x - n * k.slices;
+    const int nt = blockIdx.y;
+    const int row = lane & 31, kg = lane >> 5;
+    const int p = slice * k.px_per_block + wave * 32 + row;                    // pixel within the sample
+    const int nks = k.C >> 4;
+    const char* ap = reinterpret_cast<const char*>(k.in + ((size_t)n * k.HW + p) * k.C + 8 * kg);
+    const char* bp = static_cast<const char*>(k.w) + (((size_t)nt * 128 + lane) << 4);
+    const size_t bks = (size_t)k.ntiles * 128 * 16;                            // bytes per k-step of the packed weights
+    const int co = nt * 32 + row;                                              // this lane's output channel
+    // accumulator register r holds pixel wave*32 + (r & 3) + 8 * (r >> 2) + 4 * kg of the block
+    const size_t obase = ((size_t)n * k.HW + slice * k.px_per_block + wave * 32 + 4 * kg) * k.Cout + co;
+
+    f32x4 a0[KSB], a1[KSB], bh[KSB], bl[KSB];
+    auto issue = [&](const int ks0) {
+#pragma unroll
+        for (int i = 0; i < KSB; ++i) {
+            const int ks = min(ks0 + i, nks - 1);                              // clamped: the loads stay unconditional
+            a0[i] = load16_global(ap + ks * 64);
+            a1[i] = load16_global(ap + ks * 64 + 16);
+            bh[i] = load16_global(bp + ks * bks);
+            bl[i] = load16_global(bp + ks * bks + 1024);
+        }
+    };
+    issue(0);
+    float rs[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rs[r] = 0.f;
+    if (k.resid) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rs[r] = k.resid[obase + (size_t)((r & 3) + 8 * (r >> 2)) * k.Cout];
+    }
+    const float add = k.bias ? k.bias[co] : 0.f;
+    const float wsc = k.wscale[co];
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int ks0 = 0; ks0 < nks; ks0 += KSB) {
+#pragma unroll
+        for (int i = 0; i < KSB; ++i) {
+            if (ks0 + i < nks) {                                               // uniform
+                unsigned h[4], l[4];
+                split2_f16(a0[i][0] * ACT_PRESCALE, a0[i][1] * ACT_PRESCALE, h[0], l[0]);
+                split2_f16(a0[i][2] * ACT_PRESCALE, a0[i][3] * ACT_PRESCALE, h[1], l[1]);
+                split2_f16(a1[i][0] * ACT_PRESCALE, a1[i][1] * ACT_PRESCALE, h[2], l[2]);
+                split2_f16(a1[i][2] * ACT_PRESCALE, a1[i][3] * ACT_PRESCALE, h[3], l[3]);
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 hv = {h[0], h[1], h[2], h[3]}, lv = {l[0], l[1], l[2], l[3]};
+                const f16x8 ah = __builtin_bit_cast(f16x8, hv), al = __builtin_bit_cast(f16x8, lv);
+                const f16x8 wh = __builtin_bit_cast(f16x8, bh[i]), wl = __builtin_bit_cast(f16x8, bl[i]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh, acc, 0, 0, 0);
+            }
+        }
+        if (ks0 + KSB < nks) issue(ks0 + KSB);                                 // wide inputs (C > 16 * KSB): next batch
+    }
+
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float v = fmaf(acc[r], wsc, add);                                      // wsc is a power of two: exact product
+        if (k.resid) v += rs[r];
+        k.out[obase + (size_t)((r & 3) + 8 * (r >> 2)) * k.Cout] = v;
+        t1 += v;
+        t2 = fmaf(v, v, t2);
+    }
+    if (k.out_stats) {
+        __shared__ double red[4 * 32 * 2];
+        double v1 = (double)t1, v2 = (double)t2;
+        v1 += __shfl_xor(v1, 32);
+        v2 += __shfl_xor(v2, 32);
+        if (lane < 32) { red[(wave * 32 + lane) * 2] = v1; red[(wave * 32 + lane) * 2 + 1] = v2; }
+        __syncthreads();
+        if (tid < 32) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int w = 0; w < nwaves; ++w) { s1 += red[(w * 32 + tid) * 2]; s2 += red[(w * 32 + tid) * 2 + 1]; }
+            double* o = k.out_stats + (((size_t)n * k.slices + slice) * k.Cout + nt * 32 + tid) * 2;
+            o[0] = s1; o[1] = s2;
+        }
+    }
+}
+
+// plain 1x1 conv of a low-resolution tensor: the whole geometry must tile exactly (no masks in the kernel)
+bool conv1x1_eligible(const ccdm_conv_args& a, int slices) {
+    const int off = getenv("CCDM_NO_CONV1X1") ? atoi(getenv("CCDM_NO_CONV1X1")) : 0;      // A/B and test hook (read per call)
+    if (off || a.prec != CCDM_PREC_F16X3) return false;                        // (ablation bits in prec: general kernel)
+    if (a.ksize != 1 || a.stride != 1 || a.up || a.stats0 || a.act != CCDM_ACT_NONE || a.film || a.skip0 || a.emb_off >= 0 || a.in1) return false;
+    const int HW = a.Hout * a.Wout;
+    if (a.C0 % 16 || a.Cout % 32 || HW % (slices * 32)) return false;
+    const int waves = HW / slices / 32;
+    return waves >= 1 && waves <= 4 && (long long)a.N * slices * (a.Cout / 32) <= 4096;      // low-resolution stages only (<= 128 pixels per slice)
+}
+
+int launch_conv1x1(const ccdm_conv_args& a, int slices, int ntiles, const float* wscale, hipStream_t s) {
+    Conv1x1K k;
+    k.in = a.in0; k.w = a.w; k.wscale = wscale; k.bias = a.bias; k.resid = a.resid; k.out = a.out; k.out_stats = a.out_stats;
+    k.C = a.C0; k.Cout = a.Cout; k.HW = a.Hout * a.Wout; k.slices = slices; k.ntiles = ntiles;
+    k.px_per_block = k.HW / slices;
+    const dim3 grid(a.N * slices, a.Cout / 32), block(k.px_per_block / 32 * 64);
+    hipLaunchKernelGGL((k_conv1x1<8>), grid, block, 0, s, k);
+    return 0;
+}
+
+}  // namespace ccdm

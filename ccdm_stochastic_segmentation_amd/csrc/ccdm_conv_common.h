@@ -55,6 +55,10 @@ struct ConvK {   // kernel-side copy of ccdm_conv_args (+ derived)
     unsigned long long* timeline;   // diagnostics (CCDM_PC_TIMELINE=1): s_memtime stamps of one mid-grid block, else NULL
 };
 
+// plain 1x1 conv (+bias +residual +statistics) of a low-resolution tensor without LDS staging (ccdm_conv1x1.hip)
+bool conv1x1_eligible(const ccdm_conv_args& a, int slices);
+int launch_conv1x1(const ccdm_conv_args& a, int slices, int ntiles, const float* wscale, hipStream_t s);
+
 // producer/consumer form of the full-width 3x3 stages (ccdm_conv_pc.hip)
 bool conv_pc_eligible(const ConvK& k, const ConvGeo& g, int NI);
 int launch_conv_pc(const ConvK& k, hipStream_t s);

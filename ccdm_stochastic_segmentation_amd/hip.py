@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("CCDM_LIB") or os.path.join(_HERE, "libccdm_hip.so")      # CCDM_LIB: A/B two builds on one GPU box
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["ccdm_conv.hip", "ccdm_conv_pc.hip", "ccdm_misc.hip", "ccdm_attention.hip", "ccdm_attn_block.hip", "ccdm_sampler.hip", "ccdm_metrics.hip", "ccdm_engine.hip"]
+SOURCES = ["ccdm_conv.hip", "ccdm_conv_pc.hip", "ccdm_conv1x1.hip", "ccdm_misc.hip", "ccdm_attention.hip", "ccdm_attn_block.hip", "ccdm_sampler.hip", "ccdm_metrics.hip", "ccdm_engine.hip"]
 # -amdgpu-mfma-vgpr-form: MFMA accumulators stay in the (unified) VGPR file.  The default heuristic parks them in AccVGPRs and pays a
 # v_accvgpr_read/_write for every vector op that touches a score or an output accumulator: 240 extra instructions per key tile in
 # the attention kernels (2066 in ccdm_attention.hip, 576 in ccdm_attn_block.hip; the conv kernels have none either way).

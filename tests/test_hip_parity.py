@@ -184,6 +184,33 @@ def test_conv_latency_slicing(U, c0, cout, H, W, k, stride, up):
         np.testing.assert_allclose(y1.cpu().numpy(), y0.cpu().numpy(), rtol=0, atol=2e-6)
 
 
+@pytest.mark.parametrize("cin,cout,H,W,resid", [(128, 128, 8, 8, 1), (96, 96, 16, 16, 1), (256, 128, 8, 8, 0), (64, 160, 16, 8, 1), (32, 32, 8, 8, 1)])
+def test_plain_1x1_conv_kernel(U, cin, cout, H, W, resid, monkeypatch):
+    """AttentionBlock.proj_out + residual (unet.py:300,311) on the LDS-free 1x1 kernel (ccdm_conv1x1.hip): against the fp64 operator,
+    bit-identical to the general conv kernel's 1x1 path (same products, same order), statistics = those of what was stored."""
+    rng = np.random.default_rng(cin + cout + H)
+    N = 3
+    x = rnd(rng, N, cin, H, W) * 1.4 + 0.1
+    w = rnd(rng, cout, cin, 1, 1) / np.sqrt(cin)
+    b = rnd(rng, cout, scale=0.1)
+    res = rnd(rng, N, cout, H, W) if resid else None
+    ref = F.conv2d(x.double(), w.double(), b.double()) + (res.double() if resid else 0)
+    xs, rs_ = U.nhwc(x), (U.nhwc(res) if resid else None)
+    monkeypatch.delenv("CCDM_NO_CONV1X1", raising=False)
+    out, ost = U.conv2d([xs], w.numpy(), b.numpy(), 1, resid=rs_, prec=hip.PREC_F16X3)
+    monkeypatch.setenv("CCDM_NO_CONV1X1", "1")
+    gen, gst = U.conv2d([xs], w.numpy(), b.numpy(), 1, resid=rs_, prec=hip.PREC_F16X3)
+    monkeypatch.delenv("CCDM_NO_CONV1X1")
+    got = U.bchw(out)
+    np.testing.assert_allclose(got.numpy(), ref.float().numpy(), rtol=0, atol=2e-5)
+    assert torch.equal(out, gen)
+    gd = got.double()
+    st = ost.cpu().sum(1)
+    np.testing.assert_allclose(st[..., 0].numpy(), gd.sum((2, 3)).numpy(), rtol=0, atol=2e-6 * gd.abs().sum((2, 3)).max().item())
+    np.testing.assert_allclose(st[..., 1].numpy(), (gd * gd).sum((2, 3)).numpy(), rtol=2e-6, atol=0)
+    np.testing.assert_allclose(st.numpy(), gst.cpu().sum(1).numpy(), rtol=2e-6, atol=1e-4)
+
+
 def test_upsample_conv_subpixel_form_refusals(U):
     lib = hip.load()
     assert lib.ccdm_upconv_supported(64, 64, hip.PREC_F16X3) == 1
