@@ -238,8 +238,16 @@ __global__ void k_stats_fold(const double* __restrict__ in, int S_in, int C2, in
     const int j = i / C2, c = i % C2;
     const int s0 = (int)((long long)j * S_in / S_out), s1 = (int)((long long)(j + 1) * S_in / S_out);
     const double* p = in + (size_t)n * S_in * C2 + c;
+    // 16 independent loads per round (clamped; added in ascending order, masked): a 384 -> 16 fold is 2 memory round trips instead of
+    // 24 dependent ones (17 -> ~4 us per launch; a 512x1024 step has 25 of them)
     double t = 0.0;
-    for (int s = s0; s < s1; ++s) t += p[(size_t)s * C2];
+    for (int s = s0; s < s1; s += 16) {
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = p[(size_t)min(s + u, s1 - 1) * C2];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t += s + u < s1 ? v[u] : 0.0;
+    }
     out[(size_t)n * S_out * C2 + i] = t;
 }
 int launch_stats_fold(const double* in, int N, int S_in, int C, int S_out, double* out, hipStream_t s) {
