@@ -32,8 +32,9 @@ struct Conv1x1K {
 };
 
 // KSB k-steps (16 channels each) are in flight at a time: C <= 16 * KSB runs with every load issued up front
-template <int KSB>
-__global__ __launch_bounds__(256) void k_conv1x1(const Conv1x1K k) {
+// (MAXT: the block size bound the register budget is planned for — 4 waves with 8 k-steps in flight, 16 waves with 4)
+template <int KSB, int MAXT>
+__global__ __launch_bounds__(MAXT) void k_conv1x1(const Conv1x1K k) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nwaves = blockDim.x >> 6;
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256) void k_conv1x1(const Conv1x1K k) {
         t2 = fmaf(v, v, t2);
     }
     if (k.out_stats) {
-        __shared__ double red[4 * 32 * 2];
+        __shared__ double red[(MAXT / 64) * 32 * 2];
         double v1 = (double)t1, v2 = (double)t2;
         v1 += __shfl_xor(v1, 32);
         v2 += __shfl_xor(v2, 32);
@@ -128,7 +129,7 @@ bool conv1x1_eligible(const ccdm_conv_args& a, int slices) {
     const int HW = a.Hout * a.Wout;
     if (a.C0 % 16 || a.Cout % 32 || HW % (slices * 32)) return false;
     const int waves = HW / slices / 32;
-    return waves >= 1 && waves <= 4 && (long long)a.N * slices * (a.Cout / 32) <= 4096;      // low-resolution stages only (<= 128 pixels per slice)
+    return waves >= 1 && waves <= 16 && (long long)a.N * slices * (a.Cout / 32) <= 4096;     // low-resolution stages only (<= 512 pixels per slice)
 }
 
 int launch_conv1x1(const ccdm_conv_args& a, int slices, int ntiles, const float* wscale, hipStream_t s) {
@@ -137,7 +138,8 @@ int launch_conv1x1(const ccdm_conv_args& a, int slices, int ntiles, const float*
     k.C = a.C0; k.Cout = a.Cout; k.HW = a.Hout * a.Wout; k.slices = slices; k.ntiles = ntiles;
     k.px_per_block = k.HW / slices;
     const dim3 grid(a.N * slices, a.Cout / 32), block(k.px_per_block / 32 * 64);
-    hipLaunchKernelGGL((k_conv1x1<8>), grid, block, 0, s, k);
+    if (block.x <= 256) hipLaunchKernelGGL((k_conv1x1<8, 256>), grid, block, 0, s, k);
+    else hipLaunchKernelGGL((k_conv1x1<4, 1024>), grid, block, 0, s, k);
     return 0;
 }
 

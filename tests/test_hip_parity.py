@@ -184,7 +184,8 @@ def test_conv_latency_slicing(U, c0, cout, H, W, k, stride, up):
         np.testing.assert_allclose(y1.cpu().numpy(), y0.cpu().numpy(), rtol=0, atol=2e-6)
 
 
-@pytest.mark.parametrize("cin,cout,H,W,resid", [(128, 128, 8, 8, 1), (96, 96, 16, 16, 1), (256, 128, 8, 8, 0), (64, 160, 16, 8, 1), (32, 32, 8, 8, 1)])
+@pytest.mark.parametrize("cin,cout,H,W,resid", [(128, 128, 8, 8, 1), (96, 96, 16, 16, 1), (256, 128, 8, 8, 0), (64, 160, 16, 8, 1), (32, 32, 8, 8, 1),
+                                                 (256, 256, 16, 32, 1), (128, 128, 32, 64, 1)])
 def test_plain_1x1_conv_kernel(U, cin, cout, H, W, resid, monkeypatch):
     """AttentionBlock.proj_out + residual (unet.py:300,311) on the LDS-free 1x1 kernel (ccdm_conv1x1.hip): against the fp64 operator,
     bit-identical to the general conv kernel's 1x1 path (same products, same order), statistics = those of what was stored."""
