@@ -1,5 +1,6 @@
-// Plain 1x1 conv (+bias +residual, + per-channel output statistics) of a low-resolution tensor, F16X3 arithmetic:
-// AttentionBlock.proj_out + the block's residual (reference unet.py:300,311) — 11 launches per LIDC denoise step.
+// 1x1 conv ([GroupNorm ->] conv +bias +residual, + per-channel output statistics) of a low-resolution tensor, F16X3 arithmetic:
+// AttentionBlock.proj_out + the block's residual (reference unet.py:300,311) — 11 launches per LIDC denoise step — and, where the
+// norm+qkv+attention kernel does not apply (T > 256: Cityscapes sizes), AttentionBlock.norm + qkv (unet.py:291-299,306).
 //
 // The general kernel (ccdm_conv.hip) stages every input through LDS — two barrier-separated round trips per channel chunk,
 // a halo walk, a commit pass — which is what a 3x3 conv with GroupNorm on load needs and what a 64-pixel x 128-channel GEMM
@@ -28,13 +29,18 @@ struct Conv1x1K {
     const float* resid;     // [N, HW, Cout] or NULL
     float* out;             // [N, HW, Cout]
     double* out_stats;      // [N, slices, Cout, 2] or NULL
-    int C, Cout, HW, slices, ntiles, px_per_block;
+    int C, Cout, HW, slices, ntiles, px_per_block;   // slices = pixel blocks per sample (= statistics slices when out_stats is written)
+    ccdm_conv_args a;       // GroupNorm operands (stats0, slices0, gamma, beta, eps, Hin, Win) for the GN variant
 };
 
 // KSB k-steps (16 channels each) are in flight at a time: C <= 16 * KSB runs with every load issued up front
 // (MAXT: the block size bound the register budget is planned for — 4 waves with 8 k-steps in flight, 16 waves with 4)
-template <int KSB, int MAXT>
+// GN: the input is normalised on load — (scale, shift) table of this sample in LDS, built in the prologue from the producer's
+// statistics partials exactly like ccdm_conv.hip does (gn_prefetch / gn_affine_block), one fma per element before the split.
+template <int KSB, int MAXT, bool GN>
 __global__ __launch_bounds__(MAXT) void k_conv1x1(const Conv1x1K k) {
+    extern __shared__ __attribute__((aligned(16))) char smem1[];
+    float2* ab = reinterpret_cast<float2*>(smem1);                             // [C] (GN only)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nwaves = blockDim.x >> 6;
@@ -50,6 +56,8 @@ __global__ __launch_bounds__(MAXT) void k_conv1x1(const Conv1x1K k) {
     // accumulator register r holds pixel wave*32 + (r & 3) + 8 * (r >> 2) + 4 * kg of the block
     const size_t obase = ((size_t)n * k.HW + slice * k.px_per_block + wave * 32 + 4 * kg) * k.Cout + co;
 
+    GnPrefetch gpf;
+    if (GN) gn_prefetch(k.a, true, n, 0, min(tid, k.C - 1), k.w, gpf);         // ahead of the operand loads, consumed behind them
     f32x4 a0[KSB], a1[KSB], bh[KSB], bl[KSB];
     auto issue = [&](const int ks0) {
 #pragma unroll
@@ -71,6 +79,11 @@ __global__ __launch_bounds__(MAXT) void k_conv1x1(const Conv1x1K k) {
     }
     const float add = k.bias ? k.bias[co] : 0.f;
     const float wsc = k.wscale[co];
+    if (GN) {
+        gn_affine_block(k.a, n, 0, gpf, reinterpret_cast<f64x2*>(smem1 + (size_t)k.C * 8), ab);
+        __syncthreads();
+    }
+    const float2* abl = ab + 8 * kg;
 
     f32x16 acc;
 #pragma unroll
@@ -80,10 +93,19 @@ __global__ __launch_bounds__(MAXT) void k_conv1x1(const Conv1x1K k) {
         for (int i = 0; i < KSB; ++i) {
             if (ks0 + i < nks) {                                               // uniform
                 unsigned h[4], l[4];
-                split2_f16(a0[i][0] * ACT_PRESCALE, a0[i][1] * ACT_PRESCALE, h[0], l[0]);
-                split2_f16(a0[i][2] * ACT_PRESCALE, a0[i][3] * ACT_PRESCALE, h[1], l[1]);
-                split2_f16(a1[i][0] * ACT_PRESCALE, a1[i][1] * ACT_PRESCALE, h[2], l[2]);
-                split2_f16(a1[i][2] * ACT_PRESCALE, a1[i][3] * ACT_PRESCALE, h[3], l[3]);
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float v = j < 4 ? a0[i][j] : a1[i][j - 4];
+                    if (GN) {                                                  // same roundings as the general kernel: (scale, shift) * 2^4 exactly, one fma
+                        const float2 t = abl[16 * (ks0 + i) + j];
+                        x[j] = fmaf(v, t.x * ACT_PRESCALE, t.y * ACT_PRESCALE);
+                    } else x[j] = v * ACT_PRESCALE;
+                }
+                split2_f16(x[0], x[1], h[0], l[0]);
+                split2_f16(x[2], x[3], h[1], l[1]);
+                split2_f16(x[4], x[5], h[2], l[2]);
+                split2_f16(x[6], x[7], h[3], l[3]);
                 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                 const u32x4 hv = {h[0], h[1], h[2], h[3]}, lv = {l[0], l[1], l[2], l[3]};
                 const f16x8 ah = __builtin_bit_cast(f16x8, hv), al = __builtin_bit_cast(f16x8, lv);
@@ -121,25 +143,43 @@ __global__ __launch_bounds__(MAXT) void k_conv1x1(const Conv1x1K k) {
     }
 }
 
-// plain 1x1 conv of a low-resolution tensor: the whole geometry must tile exactly (no masks in the kernel)
+// pixels per block: one statistics slice when statistics are written (<= 512 pixels: 16 waves), else 128 / 64 / 32 (any that divides HW)
+static int conv1x1_px_per_block(const ccdm_conv_args& a, int slices) {
+    const int HW = a.Hout * a.Wout;
+    if (a.out_stats) return (HW % (slices * 32) == 0 && HW / slices <= 512) ? HW / slices : 0;
+    for (int p = 128; p >= 32; p >>= 1)
+        if (HW % p == 0) return p;
+    return 0;
+}
+
+// 1x1 conv of a low-resolution tensor: the whole geometry must tile exactly (no masks in the kernel)
 bool conv1x1_eligible(const ccdm_conv_args& a, int slices) {
     const int off = getenv("CCDM_NO_CONV1X1") ? atoi(getenv("CCDM_NO_CONV1X1")) : 0;      // A/B and test hook (read per call)
     if (off || a.prec != CCDM_PREC_F16X3) return false;                        // (ablation bits in prec: general kernel)
-    if (a.ksize != 1 || a.stride != 1 || a.up || a.stats0 || a.act != CCDM_ACT_NONE || a.film || a.skip0 || a.emb_off >= 0 || a.in1) return false;
+    if (a.ksize != 1 || a.stride != 1 || a.up || a.act != CCDM_ACT_NONE || a.film || a.skip0 || a.emb_off >= 0 || a.in1) return false;
     const int HW = a.Hout * a.Wout;
-    if (a.C0 % 16 || a.Cout % 32 || HW % (slices * 32)) return false;
-    const int waves = HW / slices / 32;
-    return waves >= 1 && waves <= 16 && (long long)a.N * slices * (a.Cout / 32) <= 4096;     // low-resolution stages only (<= 512 pixels per slice)
+    if (a.C0 % 16 || a.Cout % 32 || a.C0 > CCDM_MAX_CHANNELS) return false;
+    const int ppb = conv1x1_px_per_block(a, slices);
+    if (a.stats0 && ppb > 128) return false;                                   // the GroupNorm variant is planned for 4-wave blocks (registers)
+    return ppb > 0 && (long long)a.N * (HW / ppb) * (a.Cout / 32) <= 8192;      // low-resolution stages only
 }
 
 int launch_conv1x1(const ccdm_conv_args& a, int slices, int ntiles, const float* wscale, hipStream_t s) {
     Conv1x1K k;
     k.in = a.in0; k.w = a.w; k.wscale = wscale; k.bias = a.bias; k.resid = a.resid; k.out = a.out; k.out_stats = a.out_stats;
-    k.C = a.C0; k.Cout = a.Cout; k.HW = a.Hout * a.Wout; k.slices = slices; k.ntiles = ntiles;
-    k.px_per_block = k.HW / slices;
-    const dim3 grid(a.N * slices, a.Cout / 32), block(k.px_per_block / 32 * 64);
-    if (block.x <= 256) hipLaunchKernelGGL((k_conv1x1<8, 256>), grid, block, 0, s, k);
-    else hipLaunchKernelGGL((k_conv1x1<4, 1024>), grid, block, 0, s, k);
+    k.C = a.C0; k.Cout = a.Cout; k.HW = a.Hout * a.Wout; k.ntiles = ntiles;
+    k.px_per_block = conv1x1_px_per_block(a, slices);
+    k.slices = k.HW / k.px_per_block;
+    k.a = a;
+    const dim3 grid(a.N * k.slices, a.Cout / 32), block(k.px_per_block / 32 * 64);
+    const size_t lds = a.stats0 ? (size_t)a.C0 * 24 : 0;                        // (scale, shift) table + the statistics exchange
+    if (a.stats0) {
+        if (block.x <= 256) hipLaunchKernelGGL((k_conv1x1<8, 256, true>), grid, block, lds, s, k);
+        else hipLaunchKernelGGL((k_conv1x1<4, 1024, true>), grid, block, lds, s, k);
+    } else {
+        if (block.x <= 256) hipLaunchKernelGGL((k_conv1x1<8, 256, false>), grid, block, 0, s, k);
+        else hipLaunchKernelGGL((k_conv1x1<4, 1024, false>), grid, block, 0, s, k);
+    }
     return 0;
 }
 

@@ -212,6 +212,28 @@ def test_plain_1x1_conv_kernel(U, cin, cout, H, W, resid, monkeypatch):
     np.testing.assert_allclose(st.numpy(), gst.cpu().sum(1).numpy(), rtol=2e-6, atol=1e-4)
 
 
+@pytest.mark.parametrize("cin,cout,H,W", [(128, 384, 32, 64), (256, 768, 16, 32), (96, 288, 16, 16), (128, 384, 64, 128)])
+def test_norm_qkv_1x1_conv_kernel(U, cin, cout, H, W, monkeypatch):
+    """AttentionBlock.norm + qkv (unet.py:291-299,306) where the fused attention kernel does not apply: GroupNorm on load in the
+    LDS-free 1x1 kernel — against the fp64 operator and bit-identical to the general conv kernel."""
+    rng = np.random.default_rng(cin + H)
+    N = 2
+    x = rnd(rng, N, cin, H, W) * 1.7 - 0.4
+    w = rnd(rng, cout, cin, 1, 1) / np.sqrt(cin)
+    b = rnd(rng, cout, scale=0.1)
+    g, be = 1 + rnd(rng, cin, scale=0.2), rnd(rng, cin, scale=0.2)
+    ref = F.conv2d(F.group_norm(x.double(), 32, g.double(), be.double(), 1e-5), w.double(), b.double())
+    xs = U.nhwc(x)
+    st = U.gn_stats(xs, 4)
+    monkeypatch.delenv("CCDM_NO_CONV1X1", raising=False)
+    out, _ = U.conv2d([xs], w.numpy(), b.numpy(), 1, stats=[st], gamma=g.numpy(), beta=be.numpy(), prec=hip.PREC_F16X3, want_stats=False)
+    monkeypatch.setenv("CCDM_NO_CONV1X1", "1")
+    gen, _ = U.conv2d([xs], w.numpy(), b.numpy(), 1, stats=[st], gamma=g.numpy(), beta=be.numpy(), prec=hip.PREC_F16X3, want_stats=False)
+    monkeypatch.delenv("CCDM_NO_CONV1X1")
+    np.testing.assert_allclose(U.bchw(out).numpy(), ref.float().numpy(), rtol=0, atol=3e-5)
+    assert torch.equal(out, gen)
+
+
 def test_upsample_conv_subpixel_form_refusals(U):
     lib = hip.load()
     assert lib.ccdm_upconv_supported(64, 64, hip.PREC_F16X3) == 1
