@@ -1394,18 +1394,18 @@ def test_norm_qkv_attention_is_what_the_engine_runs(U, lidc_model):
 
 
 def test_stats_fold_and_large_image_slices(U):
-    """Images beyond 128x128 leave more statistics slices than a GroupNorm consumer reads (one per workgroup: 24 at 128x256);
-    ccdm_stats_fold reduces them to 16 in a fixed order and the folded sums equal the tensor's sums."""
+    """Images beyond 128x128 leave more statistics slices (one per workgroup: 32 at 128x256, 96 at 256x512); ccdm_stats_fold reduces
+    them to 16 in a fixed order and the folded sums equal the tensor's sums."""
     lib = hip.load()
-    assert lib.ccdm_conv_slices(128, 128, 1, 3) == 12 and lib.ccdm_conv_slices(128, 256, 1, 3) == 24
+    assert lib.ccdm_conv_slices(128, 128, 1, 3) == 12 and lib.ccdm_conv_slices(128, 256, 1, 3) == 32 and lib.ccdm_conv_slices(64, 128, 1, 3) == 32
     assert lib.ccdm_conv_slices(256, 512, 1, 3) == 96 and lib.ccdm_conv_slices(512, 1024, 1, 3) == 384
     rng = np.random.default_rng(12)
     x = rnd(rng, 2, 32, 128, 256)
     w = rnd(rng, 32, 32, 3, 3, scale=1 / np.sqrt(288))
     out, st = U.conv2d([U.nhwc(x)], w.numpy(), np.zeros(32, dtype=np.float32), 3, prec=hip.PREC_F16X3)
-    assert st.shape[1] == 24
+    assert st.shape[1] == 32
     folded = torch.empty((2, 16, 32, 2), dtype=torch.float64, device=U.DEV)
-    hip.check(lib.ccdm_stats_fold(st.data_ptr(), 2, 24, 32, 16, folded.data_ptr(), 0), "stats_fold")
+    hip.check(lib.ccdm_stats_fold(st.data_ptr(), 2, 32, 32, 16, folded.data_ptr(), 0), "stats_fold")
     U.sync()
     y = U.bchw(out).double()
     tot = folded.cpu().sum(1)
