@@ -143,6 +143,115 @@ __global__ __launch_bounds__(MAXT) void k_conv1x1(const Conv1x1K k) {
     }
 }
 
+// Several output-channel tiles per block (wide outputs on few pixels: qkv has 3C channels): the block's A fragments — loaded,
+// normalised and split ONCE — stay in registers while the block walks `ntb` consecutive n-tiles, fetching each tile's packed B
+// fragments (the next tile's while the current one multiplies).  No output statistics (qkv has no consumer GroupNorm), C <= 128.
+// One n-tile per block would redo the GroupNorm table, the 64 KB of A loads and the split 12 times for a 128 -> 384 conv.
+template <bool GN>
+__global__ __launch_bounds__(256) void k_conv1x1_multi(const Conv1x1K k, const int ntb) {
+    constexpr int KSB = 8;
+    extern __shared__ __attribute__((aligned(16))) char smem1[];
+    float2* ab = reinterpret_cast<float2*>(smem1);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = blockIdx.x / k.slices, slice = blockIdx.x - n * k.slices;
+    const int row = lane & 31, kg = lane >> 5;
+    const int p = slice * k.px_per_block + wave * 32 + row;
+    const int nks = k.C >> 4;
+    const char* ap = reinterpret_cast<const char*>(k.in + ((size_t)n * k.HW + p) * k.C + 8 * kg);
+    const size_t bks = (size_t)k.ntiles * 128 * 16;
+    const int nt_real = k.Cout >> 5;
+    const int nt_first = blockIdx.y * ntb;
+
+    GnPrefetch gpf;
+    if (GN) gn_prefetch(k.a, true, n, 0, min(tid, k.C - 1), k.w, gpf);
+    f32x4 a0[KSB], a1[KSB];
+#pragma unroll
+    for (int i = 0; i < KSB; ++i) {
+        const int ks = min(i, nks - 1);
+        a0[i] = load16_global(ap + ks * 64);
+        a1[i] = load16_global(ap + ks * 64 + 16);
+    }
+    f32x4 bh[2][KSB], bl[2][KSB];
+    auto issueB = [&](const int buf, const int nt) {
+        const char* bp = static_cast<const char*>(k.w) + (((size_t)min(nt, nt_real - 1) * 128 + lane) << 4);
+#pragma unroll
+        for (int i = 0; i < KSB; ++i) {
+            const int ks = min(i, nks - 1);
+            bh[buf][i] = load16_global(bp + ks * bks);
+            bl[buf][i] = load16_global(bp + ks * bks + 1024);
+        }
+    };
+    issueB(0, nt_first);
+    if (GN) {
+        gn_affine_block(k.a, n, 0, gpf, reinterpret_cast<f64x2*>(smem1 + (size_t)k.C * 8), ab);
+        __syncthreads();
+    }
+    const float2* abl = ab + 8 * kg;
+    f16x8 ah[KSB], al[KSB];
+#pragma unroll
+    for (int i = 0; i < KSB; ++i) {
+        unsigned h[4], l[4];
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = j < 4 ? a0[i][j] : a1[i][j - 4];
+            if (GN) {
+                const float2 t = abl[16 * min(i, nks - 1) + j];
+                x[j] = fmaf(v, t.x * ACT_PRESCALE, t.y * ACT_PRESCALE);
+            } else x[j] = v * ACT_PRESCALE;
+        }
+        split2_f16(x[0], x[1], h[0], l[0]);
+        split2_f16(x[2], x[3], h[1], l[1]);
+        split2_f16(x[4], x[5], h[2], l[2]);
+        split2_f16(x[6], x[7], h[3], l[3]);
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 hv = {h[0], h[1], h[2], h[3]}, lv = {l[0], l[1], l[2], l[3]};
+        ah[i] = __builtin_bit_cast(f16x8, hv);
+        al[i] = __builtin_bit_cast(f16x8, lv);
+    }
+    auto tile = [&](const int buf, const int nt) {
+        const int co = nt * 32 + row;
+        const size_t obase = ((size_t)n * k.HW + slice * k.px_per_block + wave * 32 + 4 * kg) * k.Cout + co;
+        float rs[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rs[r] = 0.f;
+        if (k.resid) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rs[r] = k.resid[obase + (size_t)((r & 3) + 8 * (r >> 2)) * k.Cout];
+        }
+        const float add = k.bias ? k.bias[co] : 0.f;
+        const float wsc = k.wscale[co];
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < KSB; ++i) {
+            if (i < nks) {
+                const f16x8 wh = __builtin_bit_cast(f16x8, bh[buf][i]), wl = __builtin_bit_cast(f16x8, bl[buf][i]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], wh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], wh, acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = fmaf(acc[r], wsc, add);
+            if (k.resid) v += rs[r];
+            k.out[obase + (size_t)((r & 3) + 8 * (r >> 2)) * k.Cout] = v;
+        }
+    };
+    for (int t = 0; t < ntb; t += 2) {                                          // two n-tiles per trip: static buffer indices
+        const int nt = nt_first + t;
+        if (nt >= nt_real) break;
+        issueB(1, nt + 1);
+        tile(0, nt);
+        if (t + 1 >= ntb || nt + 1 >= nt_real) break;
+        issueB(0, nt + 2);
+        tile(1, nt + 1);
+    }
+}
+
 // pixels per block: one statistics slice when statistics are written (<= 512 pixels: 16 waves), else 128 / 64 / 32 (any that divides HW)
 static int conv1x1_px_per_block(const ccdm_conv_args& a, int slices) {
     const int HW = a.Hout * a.Wout;
@@ -173,6 +282,17 @@ int launch_conv1x1(const ccdm_conv_args& a, int slices, int ntiles, const float*
     k.a = a;
     const dim3 grid(a.N * k.slices, a.Cout / 32), block(k.px_per_block / 32 * 64);
     const size_t lds = a.stats0 ? (size_t)a.C0 * 24 : 0;                        // (scale, shift) table + the statistics exchange
+    // wide outputs without statistics (qkv): walk several n-tiles per block so that ~512 blocks remain
+    const int nt_real = a.Cout / 32;
+    const long xb = (long)a.N * k.slices;
+    int ntb = (int)((xb * nt_real + 256) / 512);
+    ntb = ntb < 1 ? 1 : (ntb > nt_real ? nt_real : ntb);
+    if (!a.out_stats && a.C0 <= 128 && block.x <= 256 && ntb > 1) {
+        const dim3 gridm((unsigned)xb, (unsigned)((nt_real + ntb - 1) / ntb));
+        if (a.stats0) hipLaunchKernelGGL((k_conv1x1_multi<true>), gridm, block, lds, s, k, ntb);
+        else hipLaunchKernelGGL((k_conv1x1_multi<false>), gridm, block, 0, s, k, ntb);
+        return 0;
+    }
     if (a.stats0) {
         if (block.x <= 256) hipLaunchKernelGGL((k_conv1x1<8, 256, true>), grid, block, lds, s, k);
         else hipLaunchKernelGGL((k_conv1x1<4, 1024, true>), grid, block, lds, s, k);
