@@ -11,7 +11,9 @@ import sys
 from collections import defaultdict
 
 src, out = sys.argv[1], sys.argv[2]
+period = int(sys.argv[3]) if len(sys.argv) > 3 else 12      # launches of the dominant (kernel, grid) per denoise step
 agg = defaultdict(lambda: defaultdict(list))
+seq = defaultdict(lambda: defaultdict(list))                 # key -> counter -> [(dispatch id, value)]: for the by-position split
 dur = defaultdict(list)
 for f in glob.glob(src + "/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
@@ -21,6 +23,7 @@ for f in glob.glob(src + "/*/*counter_collection.csv"):
         short = re.sub(r"\(.*", "", name.replace("void ", ""))
         key = f"{short} grid={r['Grid_Size']} wg={r['Workgroup_Size']}"
         agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        seq[key][r["Counter_Name"]].append((int(r["Dispatch_Id"]), float(r["Counter_Value"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
         if r["Counter_Name"] in ("GRBM_GUI_ACTIVE",):
             dur[key].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 res = {}
@@ -43,6 +46,32 @@ for key, cs in agg.items():
                                 "wait_any(waitcnt/barrier)": m.get("SQ_WAIT_ANY", 0) / wc, "wait_inst_any(issue stall)": m.get("SQ_WAIT_INST_ANY", 0) / wc}
     res[key] = e
 res = dict(sorted(res.items(), key=lambda kv: -kv[1]["launches"] * kv[1].get("mean_us_in_grbm_pass", 0)))
+# The dominant (kernel, grid) runs several layer shapes: its launches recur with `period` per denoise step, in engine-op order (bench.py's
+# roofline.kernel lists the ops), so launch i of the class belongs to position i % period.  Per-position means of the same counters:
+top = next(iter(res))
+by_pos = {}
+if res[top]["launches"] % period == 0:
+    for cname, rows in seq[top].items():
+        rows.sort()
+        for i, (_, v, us) in enumerate(rows):
+            e = by_pos.setdefault(i % period, {"n": 0, "counters": defaultdict(float), "us": 0.0, "nus": 0})
+            e["counters"][cname] += v
+            if cname == "GRBM_GUI_ACTIVE":
+                e["us"] += us; e["nus"] += 1
+    n_per = res[top]["launches"] // period
+    out_pos = {}
+    for pos, e in sorted(by_pos.items()):
+        m = {k: v / n_per for k, v in e["counters"].items()}
+        o = {"mean_us_in_grbm_pass": e["us"] / max(e["nus"], 1)}
+        if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
+            o["hbm_read_MB"] = 2 * m["FETCH_SIZE"] * 1024 / 1e6
+            o["hbm_write_MB"] = m["WRITE_SIZE"] * 1024 / 1e6
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in m and m.get("GRBM_GUI_ACTIVE", 0) > 0:
+            o["mfma_busy"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (m["GRBM_GUI_ACTIVE"] / 8 * 1024)
+            o["valu_active"] = 4 * m.get("SQ_ACTIVE_INST_VALU", 0) / (m["GRBM_GUI_ACTIVE"] / 8 * 1024)
+        o["insts_valu"], o["insts_mfma"] = m.get("SQ_INSTS_VALU"), m.get("SQ_INSTS_MFMA")
+        out_pos[str(pos)] = o
+    res[top]["by_position_in_step"] = out_pos
 json.dump({"note": __doc__, "kernels": res}, open(out, "w"), indent=1)
 for k, e in list(res.items())[:8]:
     print(k[:90], "launches", e["launches"], "us", round(e.get("mean_us_in_grbm_pass", 0), 1), "hbm MB", round(e.get("hbm_bytes", 0) / 1e6, 1),
