@@ -86,7 +86,7 @@ constexpr int min_waves(int mi, int ni, int prec, int ckt, int threads) {
 // pixel): the tap walk visits the 9 halo positions once and feeds each A fragment to the 1, 2 or 4 phases whose window contains
 // it; the phases' statistics fold into the block's one partial.  NI = 1 (8x8 inputs, where blocks are scarce): one phase per
 // block, statistics slot = slice * 4 + phase.
-template <int PREC, int CKT, int KS, int STRIDE, int TH, int TW, int WAVES, int MI, int NI, int KSP = 1, bool UP2 = false>
+template <int PREC, int CKT, int KS, int STRIDE, int TH, int TW, int WAVES, int MI, int NI, int KSP = 1, bool UP2 = false, bool SKWT = false>
 __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVES * KSP * 64)) void k_conv(const ConvK k) {
     constexpr int NT = WAVES * KSP * 64;
     static_assert(KSP == 1 || KSP == KS, "tap split is by kernel row");
@@ -114,6 +114,16 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
     constexpr bool ROW_UNIFORM = ROWS && (TW * QPP) % 64 == 0;    // a wave never straddles two core rows
     constexpr int NITEM = ROWS ? NCORE + NEDGE : (HP * QPP + NT - 1) / NT;   // staging items per thread
     static_assert(NITEM <= 32, "validity mask is 32 bits");
+    // Wide skip chunks (SKW; run-time switch k.skip_wide).  A chunk of the fused 1x1 skip segment feeds the centre tap only: it needs no
+    // halo, so the same LDS holds 32 channels of the TH x TW core pixels (144-byte pixels: 36.9 KB) + 2 k-steps of one tap's fragments
+    // (4 KB).  Half as many skip chunks — each one is two barriers, an issue and a commit phase around 12 instead of 6 MFMAs per wave,
+    // and the 16-channel skip chunks were 45 % of the tile time of a decoder ResBlock's second conv — and no staging of halo pixels.
+    // (its own instantiation, SKWT: 159 registers against the plain one's 149 — both keep 3 waves per SIMD)
+    constexpr bool SKW = SKWT && PREC != CCDM_PREC_F32 && KS == 3 && STRIDE == 1 && TW == 32 && NI == 1 && KSP == 1 && !UP2 && CKT == 16;
+    constexpr int CKS = 32, PIXS = CKS * 4 + 16, QPS = CKS / 4;
+    constexpr int NITEM_S = SKW ? TH * TW * QPS / NT : 0;          // core-only items per thread (8)
+    constexpr int NITEM_R = NITEM_S > NITEM ? NITEM_S : NITEM;    // halo register set size
+    static_assert(!SKW || (TH * TW * QPS) % NT == 0, "a wide skip chunk tiles the block");
     constexpr int A_BYTES = (HP * PIXB + 15) / 16 * 16;
     // F16X3: the chunk's B fragments, [tap][k-step] slabs of G = [ni][hi|lo][64 lanes] x 16 B, staged through registers
     // like the halo.  A pass covers MB whole slabs (or 1/DB of one); the slab index is wave-uniform.
@@ -200,8 +210,10 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
     float* epi = reinterpret_cast<float*>(halo_b) + wave_all * (MI * 32 * EPS);      // [krow][wave][MI*32][EPS]
 
     const int ntile_sp = k.tiles_x * k.tiles_y;
+    const bool skw = SKW && k.skip_wide;                        // uniform
+    const int CKSK = skw ? CKS : CK;                            // channels per skip chunk
     const int nchunk_main = k.cin_pad / CK;
-    const int nchunk = nchunk_main + k.cin_pad_skip / CK;      // main segment, then the fused 1x1 skip segment
+    const int nchunk = nchunk_main + k.cin_pad_skip / CKSK;    // main segment, then the fused 1x1 skip segment
     const int my_tiles = (ntile_sp - slice + k.slices - 1) / k.slices;
     const int n_iter = my_tiles * nchunk;
 
@@ -231,7 +243,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
 #endif
     constexpr bool EARLY_B = CCDM_EARLY_B && !DEEP_B && PREC != CCDM_PREC_F32 && TW < 32;
     constexpr int DEPTH_B = DEEP_B ? 2 : 1;
-    f32x4 reg[DEPTH][NITEM];
+    f32x4 reg[DEPTH][NITEM_R];
     f32x4 regB[DEPTH_B][NITEM_B > 0 ? NITEM_B : 1];
     unsigned valid[DEPTH];         // generic walk: bit i = item i lies inside the image
     unsigned rowmask[DEPTH];       // row-structured: bit i = core row of pass i inside the image (wave-uniform)
@@ -255,7 +267,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
     {
         const int ch = lane < nchunk ? lane : 0;
         const bool sk = ch >= nchunk_main;                       // this chunk belongs to the fused 1x1 skip segment
-        const int c0 = (sk ? ch - nchunk_main : ch) * CK;
+        const int c0 = sk ? (ch - nchunk_main) * CKSK : ch * CK;
         const int sC0 = sk ? a.SC0 : a.C0, sC1 = sk ? a.SC1 : a.C1;
         // a chunk never straddles the concat seam (launcher: C0 % CK == 0 when there is a second source)
         const bool second = sC1 > 0 && c0 >= sC0;
@@ -277,6 +289,28 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                                                          (unsigned)__builtin_amdgcn_readlane(T_lo, ch));      // uniform per-sample base
         const int ups = UP2 ? 0 : __builtin_amdgcn_readfirstlane(a.up);   // scalar shift amount (in a vector register the row math below turns vector too)
         const int oy0 = ty * TH, ox0 = tx * TW;
+        if constexpr (SKW) {
+            if (skw && ch >= nchunk_main) {
+                // wide skip chunk: the TH x TW core pixels, 8 channel quads per pixel, one row per pass (all of it wave-uniform row math)
+                unsigned t_ = tid;
+                asm volatile("" : "+v"(t_));
+                const int tq = t_ % QPS, px = t_ / QPS;
+                const unsigned c = (unsigned)cb + 4u * (unsigned)tq;
+                const unsigned cq = min(c, (unsigned)Cs - 4u);
+                const int ix = ox0 + px;
+                xok[d] = (c < (unsigned)Cs) & (ix < Wc);
+                const unsigned colb = ((unsigned)min(ix, Wc - 1) * (unsigned)Cs + cq) << 2;
+                const unsigned rowb = (unsigned)aWin * (unsigned)Cs * 4u;
+                rowmask[d] = 0;
+#pragma unroll
+                for (int i = 0; i < NITEM_S; ++i) {
+                    const int iy = oy0 + i;
+                    reg[d][i] = load16_uniform_base(srcb + (size_t)((unsigned)min(iy, Hc - 1) * rowb), colb);
+                    rowmask[d] |= (iy < Hc ? 1u : 0u) << i;
+                }
+                return;
+            }
+        }
         const bool skseg = KS > 1 && ch >= nchunk_main;           // uniform: skip-segment chunk (1x1, no halo needed)
         const int ylo = skseg ? min(oy0, Hc - 1) : 0, yhi = skseg ? min(oy0 + TH - 1, Hc - 1) : Hc - 1;
         const int xlo = skseg ? min(ox0, Wc - 1) : 0, xhi = skseg ? min(ox0 + TW - 1, Wc - 1) : Wc - 1;
@@ -365,14 +399,15 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                                                            (unsigned)__builtin_amdgcn_readlane(T_wlo, ch));
             const unsigned wtap = (unsigned)((sk ? k.cin_pad_skip : k.cin_pad) >> 4) * k.ntiles * 128;
             const unsigned wks = (unsigned)k.ntiles * 128;
-            const unsigned nslab = sk ? KST : NTAP * KST;
+            const bool skwc = SKW && skw && sk;                          // wide skip chunk: 2 k-steps of the one tap
+            const unsigned nslab = skwc ? (unsigned)(CKS / 16) : (sk ? KST : NTAP * KST);
             const unsigned remb = (B_MULTI ? t_ % G : t_) << 4;      // lane offset, 32-bit (hoisted as a 64-bit pair it defeats the saddr form)
 #pragma unroll
             for (int i = 0; i < NITEM_B; ++i) {
                 unsigned ts = B_MULTI ? i * MB + tgB : (unsigned)(i / DB);          // wave-uniform
                 const unsigned rem = B_MULTI ? remb : remb + (unsigned)(NT * (i % DB) * 16);
                 ts = ts < nslab ? ts : 0u;
-                const unsigned slab = (ts / KST) * wtap + (ts % KST) * wks;
+                const unsigned slab = skwc ? ts * wks : (ts / KST) * wtap + (ts % KST) * wks;
                 regB[DEEP_B ? d : 0][i] = load16_uniform_base(wq + ((size_t)slab << 4), rem);
             }
         }
@@ -483,8 +518,36 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
             }
         }
     };
+    // wide skip chunk: raw values (x 2^4), split, core pixel p = row * TW + px at 144-byte pitch; its two fragment slabs behind them
+    auto commit_skipw = [&](auto D_) {
+        constexpr int d = decltype(D_)::value;
+        if constexpr (SKW) {
+            unsigned t_ = tid;
+            asm volatile("" : "+v"(t_));
+            const int tq = t_ % QPS, px = t_ / QPS;
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int i = 0; i < NITEM_S; ++i) {
+                const bool ok = xok[d] & (((rowmask[d] >> i) & 1u) != 0u);
+                const f32x4 r = reg[d][i];
+                const float lim = ok ? __builtin_inff() : 0.f;         // padding -> 0 (one select per item, as in the main path)
+                const float v0 = __builtin_amdgcn_fmed3f(r[0] * ACT_PRESCALE, -lim, lim), v1 = __builtin_amdgcn_fmed3f(r[1] * ACT_PRESCALE, -lim, lim);
+                const float v2 = __builtin_amdgcn_fmed3f(r[2] * ACT_PRESCALE, -lim, lim), v3 = __builtin_amdgcn_fmed3f(r[3] * ACT_PRESCALE, -lim, lim);
+                u32x2 hi, lo;
+                unsigned h0, l0, h1, l1;
+                split2_f16(v0, v1, h0, l0);
+                split2_f16(v2, v3, h1, l1);
+                hi[0] = h0; hi[1] = h1; lo[0] = l0; lo[1] = l1;
+                char* dd = halo_b + (i * TW + px) * PIXS + 8 * tq;
+                *reinterpret_cast<u32x2*>(dd) = hi;
+                *reinterpret_cast<u32x2*>(dd + 2 * CKS) = lo;
+            }
+            reinterpret_cast<f32x4*>(halo_b + TH * TW * PIXS)[t_] = regB[0][0];      // [k-step][hi|lo][64 lanes] x 16 B: NT = 2 * 128 items
+        }
+    };
     auto commit = [&](auto D_, const int ch) {
         const bool sk = ch >= nchunk_main;
+        if (SKW && skw && sk) { commit_skipw(D_); return; }
         const int c0 = (sk ? ch - nchunk_main : ch) * CK;
         const bool gn = has_gn && !sk, act = a.act == CCDM_ACT_SILU && !sk;
         if (gn && act) commit_body(D_, std::true_type{}, std::true_type{}, c0);
@@ -594,7 +657,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
             // The fragments of step s+1 are requested before the MFMAs of step s are issued (two register sets, static
             // indices after unrolling): the LDS round trip — ~130+ cycles that an in-order wave otherwise spends idle
             // in front of every tap — runs under the previous step's matrix work.
-            constexpr bool PF = MI * NI <= 2;          // the second fragment set fits the register budget
+            constexpr bool PF = MI * NI <= 2;  // the second fragment set fits the register budget (not beside the wide skip chunks' 8-item set)
             f16x8 ah[2][MI], al[2][MI], bh[2][NI], bl[2][NI];
             auto frag_load_a = [&](const int buf, const int toff, const int ks) {
 #pragma unroll
@@ -644,9 +707,33 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                 }
             };
             if (skc) {
-                // skip segment: centre tap only, its weights are staged as B slot 0 (tap split: the centre row's group)
-                if (KSP == 1 || krow == KS / 2)
-                    walk(std::integral_constant<int, 1>{}, [&](int) { return (PAD * HWt + PAD) * PIXB; }, [&](int) { return 0; });
+                // skip segment: centre tap only, its weights staged as B slot 0 (tap split: the centre row's group).  One code path for the
+                // halo-tile form (CK channels, pixel pitch PIXB, origin at the tile's first core pixel) and the core-only form (SKW: 32
+                // channels, pitch PIXS, origin 0, its fragments behind the pixels): pitch, offsets and k-step count are run-time uniform.
+                if (KSP == 1 || krow == KS / 2) {
+                    const bool w_ = SKW && skw;
+                    const int nks = w_ ? CKS / 16 : KST, lo_off = w_ ? 2 * CKS : 2 * CK;
+                    const f16x8* bsk = w_ ? reinterpret_cast<const f16x8*>(halo_b + TH * TW * PIXS) + lane : bq;
+                    int pbs[MI];
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+                        pbs[mi] = w_ ? ((wave * MI + mi) * 32 + (lane & 31)) * PIXS + (lane >> 5) * 16 : base[mi] + (PAD * HWt + PAD) * PIXB;
+#pragma unroll 1
+                    for (int ks = 0; ks < nks; ++ks) {
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi) {
+                            const char* pa = halo_b + pbs[mi] + 32 * ks;
+                            ah[0][mi] = *reinterpret_cast<const f16x8*>(pa);
+                            al[0][mi] = *reinterpret_cast<const f16x8*>(pa + lo_off);
+                        }
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) {
+                            bh[0][ni] = bsk[(ks * NI + ni) * 128];
+                            bl[0][ni] = bsk[(ks * NI + ni) * 128 + 64];
+                        }
+                        frag_mfma(0);
+                    }
+                }
             } else if (UP2 && NI == 4) {
                 // all four phases: halo position (r, c) of the 3x3 neighbourhood is tap (r - dy, c - dx) of phase (dy, dx) when that
                 // lies in its 2x2 window — 16 (position, phase) products per k-step, each A fragment fetched once
@@ -927,6 +1014,12 @@ static int launch_geo(const ConvK& k, const ConvGeo& g, int NI, int ck, dim3 gri
             return 0;
         }
     }
+    if constexpr (PREC != CCDM_PREC_F32 && KS == 3) {
+        if (g.TW == 32 && k.skip_wide) {          // fused 1x1 skip in 32-channel core-only chunks
+            hipLaunchKernelGGL((k_conv<PREC, CK0, 3, 1, 8, 32, 4, 2, 1, 1, false, true>), grid, dim3(256), lds, s, k);
+            return 0;
+        }
+    }
     if (g.TW == 32) return launch_ni<PREC, CK0, KS, 1, 8, 32, 4, 2>(k, NI, grid, lds, s);
     if (PREC != CCDM_PREC_F32 && KS == 3 && tap_split(k.a, g)) {       // small-spatial 3x3: kernel rows split over 3 wave groups
         constexpr int KSPL = KS == 3 ? 3 : 1;
@@ -1043,6 +1136,7 @@ int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
     const int prec = a.prec & 255;
     k.cin_pad = cin_pad_for(C, prec);
     k.cin_pad_skip = a.skip0 ? cin_pad_for(a.SC0 + a.SC1, prec) : 0;
+    k.skip_wide = 0;
     int NI;
     conv_ntiles(up2 ? 4 * a.Cout : a.Cout, &k.ntiles, &NI);
     // the sub-pixel form tiles the low-resolution input space
@@ -1075,6 +1169,11 @@ int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
     }
     const int HP = ((g.TH - 1) * a.stride + a.ksize) * ((g.TW - 1) * a.stride + a.ksize);
     const int ck = chunk_ck(a, g);
+    {   // wide skip chunks (k_conv, SKW): the wide-tile F16X3 one-n-tile variant, skip sources in multiples of 32 channels
+        static const int no_skw = getenv("CCDM_NO_SKIP_WIDE") ? atoi(getenv("CCDM_NO_SKIP_WIDE")) : 0;      // same-box A/B hook
+        k.skip_wide = (!no_skw && a.skip0 && prec == CCDM_PREC_F16X3 && a.ksize == 3 && a.stride == 1 && !a.up && g.TW == 32 && NI == 1 && ck == 16 &&
+                       a.SC0 % 32 == 0 && a.SC1 % 32 == 0 && !(a.prec >> 8)) ? 1 : 0;
+    }
     {   // core halo items need no per-lane padding mask when every tile column and every channel quad exists (see ConvK)
         const int SC = a.SC0 + a.SC1;
         const bool chan_ok = a.C0 % ck == 0 && a.C1 % ck == 0 && (!a.skip0 || (a.SC0 % ck == 0 && a.SC1 % ck == 0 && SC > 0));

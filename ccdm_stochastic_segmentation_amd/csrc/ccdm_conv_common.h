@@ -49,6 +49,7 @@ struct ConvK {   // kernel-side copy of ccdm_conv_args (+ derived)
     ccdm_conv_args a;
     int cin_pad, ntiles, slices, tiles_x, tiles_y;
     int cin_pad_skip;        // padded channels of the fused 1x1 skip segment (0: none)
+    int skip_wide;           // the skip segment runs in 32-channel chunks staged core-pixels-only (wide-tile F16X3 variant, SC % 32 == 0)
     const float* wscale;     // F16X3: [ntiles*32] powers of two undoing the per-output-channel weight pre-scale
     int core_unmasked;       // every core column of every tile lies inside the image and every channel quad exists (W % TW == 0, C % CK == 0):
                              // core halo items need no per-lane padding mask, only the wave-uniform row test
