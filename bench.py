@@ -189,13 +189,15 @@ def main():
     n_tap = n // nsub
     eng = model._engine(x[:n_tap], image[:n_tap], feat[:n_tap] if feat is not None else None, slot=0)
     # The dominant kernel = the conv instantiation of the full-resolution stage: every 3x3 stride-1 conv whose output is HxW runs
-    # the same k_conv<...> symbol on the same grid (C2: 12 launches per denoise step, 41 % of its time) — the unit rocprofv3's
+    # the same k_conv<...> symbol on the same grid (C2: 9 launches per denoise step, 28 % of its time) — the unit rocprofv3's
     # per-kernel statistics report.  All of its launches are tapped; `roofline` is their aggregate (sum of algorithmic bytes
     # over sum of durations), `roofline_shapes` splits it by layer shape.
     info = eng.op_info
-    # (the Upsample conv that lands on HxW runs the sub-pixel instantiation k_conv<...,UP2> on the low-resolution grid: another symbol)
+    # (the Upsample conv that lands on HxW runs the sub-pixel instantiation k_conv<...,UP2> on the low-resolution grid, the convs with a fused
+    #  1x1 skip of 32-channel sources the core-only skip-chunk instantiation k_conv<...,SKWT>: other symbols — they appear in roofline_shapes
+    #  of the per-op pass and in the per-op table, not in this class)
     dom_ops = [i for i, o in enumerate(info) if o["kind"] == "conv" and o["k"] == 3 and o["stride"] == 1 and (o["hout"], o["wout"]) == (H, W)
-               and not o.get("subpixel")]
+               and not o.get("subpixel") and not o.get("skip_wide")]
     attn_ops = [i for i, o in enumerate(info) if o["kind"] == "attention" and o["T"] >= 2048]
     attn = max(attn_ops, key=lambda i: info[i]["T"]) if attn_ops else None
     taps = not args.graph

@@ -191,6 +191,10 @@ class SamplerEngine:
             wbytes += 4 * cout * sc
         self.op_info.append(dict(kind="conv", name=wkey, cin=cin, cout=cout, k=ksize, hin=hin, win=win, hout=hout, wout=wout,
                                  stride=stride, up=bool(up), subpixel=subpixel, gn=gn is not None, skip=skip_src is not None,
+                                 # (the launcher's rule for the core-only skip-chunk instantiation k_conv<...,SKWT>: another kernel symbol)
+                                 skip_wide=bool(skip_src is not None and self.prec == hip.PREC_F16X3 and ksize == 3 and stride == 1 and not up
+                                                and wout >= 32 and hout * wout > 512 and cout <= 32
+                                                and all(t.C % 32 == 0 for t in skip_src)),
                                  io_bytes=io, gn_read_bytes=(4 * cin * hin * win if gn is not None else 0), weight_bytes=wbytes, flop=flop))
         self._fold_stats(out)
         return out

@@ -20,4 +20,4 @@ run tcc1 FETCH_SIZE
 run tcc2 WRITE_SIZE
 run grbm GRBM_GUI_ACTIVE GRBM_COUNT
 cd $GRAFT_REPO_ROOT
-python tools/pmc_bench_summary.py $OUT gpurun_out/pmc_bench_${CFG}_$TAG.json
+python tools/pmc_bench_summary.py $OUT gpurun_out/pmc_bench_${CFG}_$TAG.json $((2 * STEPS))

@@ -11,7 +11,7 @@ import sys
 from collections import defaultdict
 
 src, out = sys.argv[1], sys.argv[2]
-period = int(sys.argv[3]) if len(sys.argv) > 3 else 12      # launches of the dominant (kernel, grid) per denoise step
+executions = int(sys.argv[3]) if len(sys.argv) > 3 else 16    # denoise steps the profiled command executed (tools/pmc_bench.sh: 2 x STEPS)
 agg = defaultdict(lambda: defaultdict(list))
 seq = defaultdict(lambda: defaultdict(list))                 # key -> counter -> [(dispatch id, value)]: for the by-position split
 dur = defaultdict(list)
@@ -50,7 +50,8 @@ res = dict(sorted(res.items(), key=lambda kv: -kv[1]["launches"] * kv[1].get("me
 # roofline.kernel lists the ops), so launch i of the class belongs to position i % period.  Per-position means of the same counters:
 top = next(iter(res))
 by_pos = {}
-if res[top]["launches"] % period == 0:
+period = res[top]["launches"] // executions if res[top]["launches"] % executions == 0 else 0      # launches of that class per denoise step
+if period > 0:
     for cname, rows in seq[top].items():
         rows.sort()
         for i, (_, v, us) in enumerate(rows):
