@@ -245,7 +245,8 @@ def test_upsample_conv_subpixel_form_refusals(U):
 
 
 @pytest.mark.parametrize("prec", PRECS, ids=PREC_IDS)
-@pytest.mark.parametrize("c0,c1,cout,H,W", [(64, 32, 32, 32, 32), (128, 96, 96, 16, 16), (256, 0, 128, 8, 8), (64, 0, 32, 40, 24)])
+@pytest.mark.parametrize("c0,c1,cout,H,W", [(64, 32, 32, 32, 32), (128, 96, 96, 16, 16), (256, 0, 128, 8, 8), (64, 0, 32, 40, 24),
+                                             (32, 32, 32, 128, 128), (32, 32, 32, 40, 72), (64, 0, 32, 33, 65), (32, 16, 32, 64, 64)])
 def test_conv_with_fused_skip(U, prec, c0, c1, cout, H, W):
     """ResBlock tail: conv3x3(SiLU(GN(h))) + b  +  conv1x1([xa|xb]) + bs in ONE launch (skip as extra K segments)."""
     rng = np.random.default_rng(c0 + cout + H)
