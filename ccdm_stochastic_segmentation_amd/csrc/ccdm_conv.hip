@@ -232,7 +232,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
 #define CCDM_DEEP_HALO 0      // same-box A/B: -1.5 % at 128x128, +4 % at 64x64 (L2 misses of the second half-lines vanish, 236 -> 174 MB fetched, time does not follow)
 #endif
     constexpr bool DEEP_B = CCDM_DEEP_PREFETCH && PREC != CCDM_PREC_F32 && CKT == 32 && 8 * (NITEM + NITEM_B) <= 136;
-    constexpr bool DEEP_A = CCDM_DEEP_HALO && PREC != CCDM_PREC_F32 && STRIDE == 1 && TW == 32 && NI == 1;
+    constexpr bool DEEP_A = CCDM_DEEP_HALO && PREC != CCDM_PREC_F32 && STRIDE == 1 && TW == 32 && NI == 1 && !SKWT;
     constexpr int DEPTH = (DEEP_A || DEEP_B) ? 2 : 1;
     // EARLY_B (experiment, off): narrow-tile variants request the NEXT chunk's weight fragments together with the next halo, right
     // after the commit has emptied the fragment registers, instead of at the top of the iteration that consumes them.  The timeline
