@@ -37,7 +37,7 @@ struct ConvGeo {
 };
 // up2: the sub-pixel upsample form tiles the low-resolution INPUT space; its blocks carry four phases of accumulators, so it
 // never takes the two-sub-tile 8x32 geometry
-static inline ConvGeo conv_geo(int Hout, int Wout, int stride, bool up2 = false) {
+static inline ConvGeo conv_geo(int Hout, int Wout, int stride, bool up2 = false, bool fine = false) {
     if (up2) return Wout >= 16 ? ConvGeo{8, 16, 4, 1} : ConvGeo{8, 8, 2, 1};
     if (stride == 2) return Wout >= 16 ? ConvGeo{8, 16, 4, 1} : ConvGeo{8, 8, 2, 1};     // (8x16: 4-wave blocks, 57 -> 49 us at 128x128 -> 64x64)
     // by image area, never by batch size (the statistics slices follow the tiling): wide tiles amortise the halo where there are
@@ -47,6 +47,7 @@ static inline ConvGeo conv_geo(int Hout, int Wout, int stride, bool up2 = false)
     //  32x32 image on 8x16 tiles costs the LIDC step 2.5 %)
     const int area = Hout * Wout;
     if (Wout >= 32 && area > 512) return {8, 32, 4, 2};
+    if (fine && area <= 256) return {8, 8, 2, 1};      // latency slicing: 16x16 images on 8x8 tiles with the tap split too (batch 8: -2 %)
     if (Wout >= 16 && area > 128) return {8, 16, 4, 1};
     return {8, 8, 2, 1};
 }

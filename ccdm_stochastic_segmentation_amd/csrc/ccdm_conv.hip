@@ -1055,7 +1055,7 @@ static int launch_prec(const ConvK& k, const ConvGeo& g, int NI, int ck, dim3 gr
 
 static int conv_slices_default(int tiles, bool up2);
 int conv_slices(int Hout, int Wout, int stride, bool up2 = false, bool fine = false) {
-    const ConvGeo g = conv_geo(Hout, Wout, stride, up2);
+    const ConvGeo g = conv_geo(Hout, Wout, stride, up2, fine);
     const int tiles = cdiv(Hout, g.TH) * cdiv(Wout, g.TW);
     const int dflt = conv_slices_default(tiles, up2);
     // latency slicing (ccdm_conv_args.fine_slices): up to CCDM_STATS_MAX_SLICES one- or two-tile workgroups per sample.  Measured on
@@ -1141,7 +1141,7 @@ int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
     conv_ntiles(up2 ? 4 * a.Cout : a.Cout, &k.ntiles, &NI);
     // the sub-pixel form tiles the low-resolution input space
     const int tH = up2 ? a.Hin : a.Hout, tW = up2 ? a.Win : a.Wout;
-    const ConvGeo g = conv_geo(tH, tW, a.stride, up2);
+    const ConvGeo g = conv_geo(tH, tW, a.stride, up2, a.fine_slices != 0);
     // small spatial stages have few pixel tiles: spread the output-channel tiles over blocks instead;
     // wide tiles take at most 2 n-tiles per block (register budget of the staged B chunk)
     if (up2) NI = g.TW == 16 ? 4 : 1;

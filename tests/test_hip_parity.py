@@ -154,7 +154,8 @@ def test_upsample_conv_subpixel_form(U, cin, cout, H, W):
 
 
 @pytest.mark.parametrize("c0,cout,H,W,k,stride,up", [(32, 32, 128, 128, 3, 1, 0), (64, 32, 64, 64, 3, 1, 0), (32, 32, 128, 128, 3, 2, 0),
-                                                     (32, 32, 64, 64, 3, 1, 2), (32, 32, 72, 40, 3, 1, 0), (96, 96, 16, 16, 1, 1, 0)])
+                                                     (32, 32, 64, 64, 3, 1, 2), (32, 32, 72, 40, 3, 1, 0), (96, 96, 16, 16, 1, 1, 0),
+                                                     (96, 96, 16, 16, 3, 1, 0)])
 def test_conv_latency_slicing(U, c0, cout, H, W, k, stride, up):
     """ccdm_conv_args.fine_slices: more, shorter workgroups per sample.  The conv output does not depend on the slicing (bit for bit);
     the statistics come out as more partials whose sum is that of the default slicing up to fp64 rounding; a GroupNorm consumer reading
