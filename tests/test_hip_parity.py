@@ -157,7 +157,8 @@ def test_upsample_conv_subpixel_form(U, cin, cout, H, W):
                                                      (32, 32, 64, 64, 3, 1, 2), (32, 32, 72, 40, 3, 1, 0), (96, 96, 16, 16, 1, 1, 0),
                                                      (96, 96, 16, 16, 3, 1, 0)])
 def test_conv_latency_slicing(U, c0, cout, H, W, k, stride, up):
-    """ccdm_conv_args.fine_slices: more, shorter workgroups per sample.  The conv output does not depend on the slicing (bit for bit);
+    """ccdm_conv_args.fine_slices: more, shorter workgroups per sample.  The conv output does not depend on the slicing (bit for bit; 16x16
+    images, which the mode also re-tiles, to fp32 rounding);
     the statistics come out as more partials whose sum is that of the default slicing up to fp64 rounding; a GroupNorm consumer reading
     32 partials per channel gives the result it gives on the default 12."""
     rng = np.random.default_rng(c0 + H + k + stride + up)
@@ -169,7 +170,11 @@ def test_conv_latency_slicing(U, c0, cout, H, W, k, stride, up):
     lib = hip.load()
     base, st0 = U.conv2d([xs], w.numpy(), b.numpy(), k, stride=stride, up=up, prec=hip.PREC_F16X3)
     fine, st1 = U.conv2d([xs], w.numpy(), b.numpy(), k, stride=stride, up=up, prec=hip.PREC_F16X3, fine=True)
-    assert torch.equal(base, fine)
+    if (H, W, k) == (16, 16, 3):
+        # latency slicing also re-tiles 16x16 images (8x8 tiles, kernel rows split over three wave groups): another summation order
+        np.testing.assert_allclose(fine.cpu().numpy(), base.cpu().numpy(), rtol=0, atol=4e-6)
+    else:
+        assert torch.equal(base, fine)
     assert st1.shape[1] >= st0.shape[1] and st1.shape[1] <= hip.STATS_MAX_SLICES
     if (H, W, stride, up) == (128, 128, 1, 0):
         assert (st0.shape[1], st1.shape[1]) == (12, 32)
