@@ -46,8 +46,10 @@ static inline ConvGeo conv_geo(int Hout, int Wout, int stride, bool up2 = false,
     // (measured: C5 shard 15.04 -> 14.63 ms, C4 7.54 -> 7.31 ms per step against the by-width rule; LIDC sizes keep their tiles, and a
     //  32x32 image on 8x16 tiles costs the LIDC step 2.5 %)
     const int area = Hout * Wout;
+    // latency slicing (ccdm_conv_args.fine_slices — the one mode whose choices may assume a small batch): 32x32 images on 8x16 tiles,
+    // 16x16 on 8x8 tiles with the tap split (batch 8: 1.56 -> 1.48 ms per LIDC denoise step; both lose at batch 64)
+    if (fine && area <= 1024) return Wout >= 16 && area > 256 ? ConvGeo{8, 16, 4, 1} : ConvGeo{8, 8, 2, 1};
     if (Wout >= 32 && area > 512) return {8, 32, 4, 2};
-    if (fine && area <= 256) return {8, 8, 2, 1};      // latency slicing: 16x16 images on 8x8 tiles with the tap split too (batch 8: -2 %)
     if (Wout >= 16 && area > 128) return {8, 16, 4, 1};
     return {8, 8, 2, 1};
 }

@@ -87,7 +87,7 @@ typedef struct ccdm_conv_args {
     const float* skip0; const float* skip1; int32_t SC0; int32_t SC1;
     const void* skip_w;
     /* 1: latency slicing — more, shorter workgroups per sample (ccdm_conv_slices_ex(..., fine = 1): up to 32 slices where the
-     * default rule gives fewer, e.g. 32 instead of 12 at 128x128; 16x16 images on 8x8 tiles) for batches too small to fill the chip.  The
+     * default rule gives fewer, e.g. 32 instead of 12 at 128x128; 32x32 images on 8x16 tiles, 16x16 on 8x8) for batches too small to fill the chip.  The
      * statistics partials — and with them the last bit of a GroupNorm — depend on the slice count, so a run is bit-reproducible
      * across batch shardings only within one slicing mode; 0 (default) is the batch-size-independent rule. */
     int32_t fine_slices;
