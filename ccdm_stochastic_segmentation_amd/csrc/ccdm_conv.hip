@@ -204,7 +204,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
         epi_wsc[ni] = PREC != CCDM_PREC_F32 ? k.wscale[min((nt0 + ni) * 32 + (lane & 31), k.ntiles * 32 - 1)] : 1.0f;   // exact power of two (per packed channel: a phase has its own)
     }
     GnPrefetch gpf;
-    gn_prefetch(a, has_gn, n, emb_row, min(tid, C - 1), a.w, gpf);
+    gn_prefetch(a, has_gn, n, emb_row, tid, NT, a.w, gpf);
     __builtin_amdgcn_sched_barrier(0);             // the requests above stay above the halo request
     constexpr int EPS = 36;                        // floats per pixel row of the transpose buffer (16-B aligned rows)
     float* epi = reinterpret_cast<float*>(halo_b) + wave_all * (MI * 32 * EPS);      // [krow][wave][MI*32][EPS]
@@ -1192,7 +1192,9 @@ int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
     const size_t epi = (size_t)g.waves * ksp * g.MI * 32 * 36 * 4;        // epilogue transpose buffer (wave-private rows)
     if (lds < epi) lds = epi;
     if (a.stats0) {
-        if (lds < (size_t)C * 16) lds = (size_t)C * 16;       // the prologue's per-channel statistics exchange (gn_affine_block) aliases the tiles
+        const size_t nthreads = (size_t)g.waves * ksp * 64;
+        const size_t ex = (size_t)C > nthreads ? (size_t)C : nthreads;          // the prologue's statistics exchange (gn_affine_block) aliases the tiles
+        if (lds < ex * 16) lds = ex * 16;
         lds += (size_t)C * 8;
     }
     if ((a.prec >> 8) & 512) lds = 60 * 1024;      // diagnostics (tools/bench_conv.py): at most 2 blocks per CU

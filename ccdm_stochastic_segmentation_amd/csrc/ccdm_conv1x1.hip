@@ -57,7 +57,7 @@ __global__ __launch_bounds__(MAXT) void k_conv1x1(const Conv1x1K k) {
     const size_t obase = ((size_t)n * k.HW + slice * k.px_per_block + wave * 32 + 4 * kg) * k.Cout + co;
 
     GnPrefetch gpf;
-    if (GN) gn_prefetch(k.a, true, n, 0, min(tid, k.C - 1), k.w, gpf);         // ahead of the operand loads, consumed behind them
+    if (GN) gn_prefetch(k.a, true, n, 0, tid, (int)blockDim.x, k.w, gpf);         // ahead of the operand loads, consumed behind them
     f32x4 a0[KSB], a1[KSB], bh[KSB], bl[KSB];
     auto issue = [&](const int ks0) {
 #pragma unroll
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void k_conv1x1_multi(const Conv1x1K k, const i
     const int nt_first = blockIdx.y * ntb;
 
     GnPrefetch gpf;
-    if (GN) gn_prefetch(k.a, true, n, 0, min(tid, k.C - 1), k.w, gpf);
+    if (GN) gn_prefetch(k.a, true, n, 0, tid, (int)blockDim.x, k.w, gpf);
     f32x4 a0[KSB], a1[KSB];
 #pragma unroll
     for (int i = 0; i < KSB; ++i) {
@@ -281,7 +281,7 @@ int launch_conv1x1(const ccdm_conv_args& a, int slices, int ntiles, const float*
     k.slices = k.HW / k.px_per_block;
     k.a = a;
     const dim3 grid(a.N * k.slices, a.Cout / 32), block(k.px_per_block / 32 * 64);
-    const size_t lds = a.stats0 ? (size_t)a.C0 * 24 : 0;                        // (scale, shift) table + the statistics exchange
+    const size_t lds = a.stats0 ? (size_t)a.C0 * 8 + (size_t)((unsigned)a.C0 > block.x ? (unsigned)a.C0 : block.x) * 16 : 0;   // (scale, shift) table + the statistics exchange
     // wide outputs without statistics (qkv): walk several n-tiles per block so that ~512 blocks remain
     const int nt_real = a.Cout / 32;
     const long xb = (long)a.N * k.slices;

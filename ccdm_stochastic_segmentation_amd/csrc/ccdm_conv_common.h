@@ -166,8 +166,22 @@ __device__ __forceinline__ const char* gn_channel_row(const ccdm_conv_args& a, i
     stride = (unsigned)Cs * 16u;
     return reinterpret_cast<const char*>(st + ((size_t)n * S * Cs + ci) * 2);
 }
-__device__ __forceinline__ void gn_prefetch(const ccdm_conv_args& a, bool has_gn, int n, int emb_row, int c, const void* dummy, GnPrefetch& g) {
+// Thread -> (channel, slot group).  A block has more threads than channels wherever many slices occur (32-64 channels on 256
+// threads at the full-resolution stages), so the first G * C threads each take 16 slices of one channel: up to 64 slices are summed
+// from ONE prefetch round.  G = min(NT / C, 4); threads beyond G * C idle (their loads are clamped duplicates).
+struct GnLane { int c, grp, G; };
+__device__ __forceinline__ GnLane gn_lane(int C, int tid, int NT) {
+    GnLane l;
+    l.G = NT >= 4 * C ? 4 : (NT >= 3 * C ? 3 : (NT >= 2 * C ? 2 : 1));
+    l.grp = (tid >= C ? 1 : 0) + (tid >= 2 * C ? 1 : 0) + (tid >= 3 * C ? 1 : 0);
+    l.c = tid - l.grp * C;
+    if (l.grp >= l.G || l.c >= C) { l.grp = l.G; l.c = C - 1; }         // idle lane (grp == G marks it)
+    return l;
+}
+__device__ __forceinline__ void gn_prefetch(const ccdm_conv_args& a, bool has_gn, int n, int emb_row, int tid, int NT, const void* dummy, GnPrefetch& g) {
     const int C = a.C0 + a.C1;
+    const GnLane l = gn_lane(C, tid, NT);
+    const int c = l.c, grp = l.grp < l.G ? l.grp : l.G - 1;
     const float* df = static_cast<const float*>(dummy);
     const bool film = has_gn && a.film;
     const float* gam = has_gn ? a.gamma + c : df;
@@ -179,43 +193,50 @@ __device__ __forceinline__ void gn_prefetch(const ccdm_conv_args& a, bool has_gn
     unsigned stride = 0;
     const char* base = static_cast<const char*>(dummy);
     if (has_gn) base = gn_channel_row(a, n, c, S, stride);               // uniform condition, selects only
-    const unsigned last = (unsigned)(S - 1) * stride;
+    const unsigned last = (unsigned)(S - 1) * stride, first = (unsigned)(16 * grp) * stride;
 #pragma unroll
-    for (int u = 0; u < 16; ++u) g.v[u] = *reinterpret_cast<const f64x2*>(base + min((unsigned)u * stride, last));
+    for (int u = 0; u < 16; ++u) g.v[u] = *reinterpret_cast<const f64x2*>(base + min(first + (unsigned)u * stride, last));
 }
-// this channel's (sum, sum^2) over its slices, ascending; g: the first 16 partials if they were prefetched, else NULL
-__device__ __forceinline__ f64x2 gn_channel_sums(const ccdm_conv_args& a, int n, int c, const GnPrefetch* g) {
+// (sum, sum^2) of channel c over the slices [16 grp, 16 grp + 16) from the prefetched values g (NULL: fetched here), ascending; the lane
+// of group 0 also takes the slices beyond 16 G (more slices than one prefetch round of the block covers: blocking loads)
+__device__ __forceinline__ f64x2 gn_channel_sums(const ccdm_conv_args& a, int n, int c, int grp, int G, const GnPrefetch* g) {
     int S;
     unsigned stride;
     const char* base = gn_channel_row(a, n, c, S, stride);
     f64x2 acc = {0.0, 0.0};
-    int s0 = 0;
+    const int s_first = 16 * grp;
     if (g) {
 #pragma unroll
         for (int u = 0; u < 16; ++u) {                                   // selects, not branches (x + 0.0 == x)
-            acc[0] += u < S ? g->v[u][0] : 0.0;
-            acc[1] += u < S ? g->v[u][1] : 0.0;
+            acc[0] += s_first + u < S ? g->v[u][0] : 0.0;
+            acc[1] += s_first + u < S ? g->v[u][1] : 0.0;
         }
-        s0 = 16;
+    } else {
+        for (int s = s_first; s < S && s < s_first + 16; ++s) acc += *reinterpret_cast<const f64x2*>(base + (unsigned)s * stride);
     }
-    for (int s = s0; s < S; ++s) acc += *reinterpret_cast<const f64x2*>(base + (unsigned)s * stride);
+    if (grp == 0)
+        for (int s = 16 * G; s < S; ++s) acc += *reinterpret_cast<const f64x2*>(base + (unsigned)s * stride);
     return acc;
 }
-// the whole table ab[0..C): call with the block's threads converged; `scratch` = C x 16 B of LDS not otherwise in use until the
-// caller's next barrier
+// the whole table ab[0..C): call with the block's threads converged; `scratch` = max(C, blockDim.x) x 16 B of LDS not otherwise in use
+// until the caller's next barrier.  Order of additions per group: channels ascending, per channel the slot groups ascending, per slot
+// group the slices ascending (for <= 16 slices: the plain ascending (channel, slice) order).
 __device__ __forceinline__ void gn_affine_block(const ccdm_conv_args& a, int n, int emb_row, const GnPrefetch& g, f64x2* scratch, float2* ab) {
     const int C = a.C0 + a.C1, cpg = C / 32;
     const int tid = threadIdx.x, NT = blockDim.x;
+    const GnLane l = gn_lane(C, tid, NT);
+    const int G = l.G;
     auto group = [&](const int c) {
         const int c_lo = (c / cpg) * cpg;
         f64x2 acc = {0.0, 0.0};
-        for (int j = 0; j < cpg; ++j) acc += scratch[c_lo + j];
+        for (int j = 0; j < cpg; ++j)
+            for (int q = 0; q < G; ++q) acc += scratch[q * C + c_lo + j];
         return acc;
     };
-    // channel tid works from the prefetched values alone — no load here, which would be younger than the caller's halo request and
-    // drag its round trip into this wait; channels beyond the block size (C > NT: rare) take blocking loads
-    if (tid < C) scratch[tid] = gn_channel_sums(a, n, tid, &g);
-    for (int c = tid + NT; c < C; c += NT) scratch[c] = gn_channel_sums(a, n, c, nullptr);
+    // the lanes of the first G * C threads work from the prefetched values alone — no load here, which would be younger than the caller's
+    // halo request and drag its round trip into this wait; channels beyond the block size (C > NT, then G = 1: rare) take blocking loads
+    if (l.grp < G) scratch[l.grp * C + l.c] = gn_channel_sums(a, n, l.c, l.grp, G, &g);
+    for (int c = tid + NT; c < C; c += NT) scratch[c] = gn_channel_sums(a, n, c, 0, 1, nullptr);
     __syncthreads();
     if (tid < C) {
         const f64x2 acc = group(tid);
