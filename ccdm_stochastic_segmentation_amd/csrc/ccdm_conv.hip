@@ -1054,14 +1054,16 @@ static int launch_prec(const ConvK& k, const ConvGeo& g, int NI, int ck, dim3 gr
 }
 
 static int conv_slices_default(int tiles, bool up2);
-int conv_slices(int Hout, int Wout, int stride, bool up2 = false, bool fine = false) {
-    const ConvGeo g = conv_geo(Hout, Wout, stride, up2, fine);
+int conv_slices(int Hout, int Wout, int stride, bool up2 = false, int fine = 0) {
+    const ConvGeo g = conv_geo(Hout, Wout, stride, up2, fine != 0);
     const int tiles = cdiv(Hout, g.TH) * cdiv(Wout, g.TW);
     const int dflt = conv_slices_default(tiles, up2);
     // latency slicing (ccdm_conv_args.fine_slices): up to CCDM_STATS_MAX_SLICES one- or two-tile workgroups per sample.  Measured on
     // the LIDC step: batch 8 2.06 -> 1.73 ms per denoise step, batch 64 3.32 -> 3.49 (every block prologue is paid per 2 tiles
     // instead of per 5.3) — hence a mode, not the rule.
-    if (fine) { const int f = tiles < CCDM_STATS_MAX_SLICES ? tiles : CCDM_STATS_MAX_SLICES; return f > dflt ? f : dflt; }
+    // level 1: up to 32 slices; level 2 (batches of <= 8): up to CCDM_STATS_MAX_SLICES = 64, i.e. one tile per block at 128x128
+    // (batch 8 1.47 -> 1.39 ms, batch 4 1.41 -> 1.28 ms per LIDC denoise step; batch 16 loses 4 % with it)
+    if (fine) { const int cap = fine >= 2 ? CCDM_STATS_MAX_SLICES : 32; const int f = tiles < cap ? tiles : cap; return f > dflt ? f : dflt; }
     return dflt;
 }
 static int conv_slices_default(int tiles, bool up2) {
@@ -1151,12 +1153,12 @@ int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
         // per CU): worth it only when there are blocks to spare.  Measured at the 32x32 stage (64 samples x 4 tiles): one n-tile
         // per block 25.6 us vs 28.0; at 64x64 outputs (16 tiles per sample) two n-tiles win, 67.8 vs 70.6.  (A partitioning
         // choice only: every output element is computed by the same instruction sequence either way.)
-        const long blocks2 = (long)a.N * conv_slices(a.Hout, a.Wout, a.stride, false, a.fine_slices != 0) * (k.ntiles / 2);
+        const long blocks2 = (long)a.N * conv_slices(a.Hout, a.Wout, a.stride, false, a.fine_slices) * (k.ntiles / 2);
         NI = (k.ntiles % 2 == 0 && blocks2 >= 512) ? 2 : 1;
     }
     k.tiles_x = cdiv(tW, g.TW);
     k.tiles_y = cdiv(tH, g.TH);
-    k.slices = conv_slices(tH, tW, a.stride, up2, a.fine_slices != 0);
+    k.slices = conv_slices(tH, tW, a.stride, up2, a.fine_slices);
     k.wscale = reinterpret_cast<const float*>(static_cast<const char*>(a.w) +
                                               (up2 ? packed_frag_bytes(4 * a.Cout, C, 2, prec) : packed_frag_bytes(a.Cout, C, a.ksize, prec)));
     const int want_slices = (up2 && NI == 1 ? 4 : 1) * k.slices;      // one phase per block: every (slice, phase) pair leaves a partial
@@ -1230,9 +1232,9 @@ extern "C" int ccdm_upconv_slices(int Hin, int Win) {
 }
 
 extern "C" int ccdm_conv_slices_ex(int Hin, int Win, int ksize, int stride, int up, int fine) {
-    if (up == 2) return (ccdm::conv_geo(Hin, Win, 1, true).TW == 16 ? 1 : 4) * ccdm::conv_slices(Hin, Win, 1, true, fine != 0);
+    if (up == 2) return (ccdm::conv_geo(Hin, Win, 1, true).TW == 16 ? 1 : 4) * ccdm::conv_slices(Hin, Win, 1, true, fine);
     const int Hc = up ? 2 * Hin : Hin, Wc = up ? 2 * Win : Win, pad = ksize / 2;
-    return ccdm::conv_slices((Hc + 2 * pad - ksize) / stride + 1, (Wc + 2 * pad - ksize) / stride + 1, stride, false, fine != 0);
+    return ccdm::conv_slices((Hc + 2 * pad - ksize) / stride + 1, (Wc + 2 * pad - ksize) / stride + 1, stride, false, fine);
 }
 
 extern "C" int ccdm_debug_read_timeline(unsigned long long* host, int n) {

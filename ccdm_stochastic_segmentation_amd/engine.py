@@ -59,9 +59,9 @@ class SamplerEngine:
 
     def __init__(self, spec: UNetSpec, state_dict: Dict[str, torch.Tensor], N: int, H: int, W: int,
                  num_classes: int, img_channels: int, device: torch.device, max_steps: int,
-                 feature_shape: Optional[Tuple[int, int, int]] = None, prec: int = hip.PREC_F32, fine_slices: bool = False):
+                 feature_shape: Optional[Tuple[int, int, int]] = None, prec: int = hip.PREC_F32, fine_slices: int = 0):
         self.lib = hip.load()
-        self.fine_slices = bool(fine_slices)       # latency slicing (ccdm_conv_args.fine_slices): more, shorter workgroups per sample
+        self.fine_slices = int(fine_slices)        # latency slicing level (ccdm_conv_args.fine_slices): more, shorter workgroups per sample
         if device.type != "cuda":
             raise hip.CcdmHipError("SamplerEngine needs a HIP device (torch device 'cuda'); there is no CPU path")
         self.spec, self.N, self.H, self.W = spec, int(N), int(H), int(W)

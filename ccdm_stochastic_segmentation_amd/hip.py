@@ -24,7 +24,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 ACT_NONE, ACT_SILU = 0, 1
 PREC_F32, PREC_F16X3 = 0, 1
 STEP_SAMPLE, STEP_LAST_CONFIDENCE, STEP_LAST_MAJORITY, STEP_LAST_KEEP, STEP_SOFTMAX_ONLY = 0, 1, 2, 3, 4
-STATS_MAX_SLICES = 32       # CCDM_STATS_MAX_SLICES: what a GroupNorm consumer reads
+STATS_MAX_SLICES = 64       # CCDM_STATS_MAX_SLICES: what a GroupNorm consumer reads
 STATS_FOLD_SLICES = 16      # CCDM_STATS_FOLD_SLICES: what the engine folds a larger slice count to
 ABI_VERSION = 4          # CCDM_ABI_VERSION of include/ccdm_hip.h
 

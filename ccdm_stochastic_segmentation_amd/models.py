@@ -289,7 +289,7 @@ class DenoisingModel(nn.Module):
         self.on_range_error = "f32"
         # workgroup slicing of the conv kernels: "throughput" (default) = the batch-size-independent rule — samples do not depend on how
         # a batch is sharded over ranks or sub-batches, bit for bit; "latency" = up to 32 one- or two-tile workgroups per sample
-        # (ccdm_conv_args.fine_slices) for batches too small to fill the chip (LIDC batch 8: 2.06 -> 1.73 ms per denoise step; batch
+        # (ccdm_conv_args.fine_slices) for batches too small to fill the chip (LIDC batch 8: 2.05 -> 1.39 ms per denoise step; batch
         # 64 loses 5 %): GroupNorm's partial sums are then added in another order, so its samples may differ from the default mode's in
         # the last bit of a probability (never between two runs of the same mode and batch split)
         self.slicing = "throughput"
@@ -299,10 +299,12 @@ class DenoisingModel(nn.Module):
     def time_steps(self) -> int:
         return self.diffusion.time_steps
 
-    def _fine_slices(self, N: int) -> bool:
+    def _fine_slices(self, N: int) -> int:
+        """ccdm_conv_args.fine_slices for a batch of N: 0 = the batch-size-independent rule; latency mode: 2 (up to 64 slices: one tile per
+        workgroup at 128x128) for N <= 8, else 1 (up to 32)."""
         if self.slicing not in ("throughput", "latency"):
             raise ValueError(f"slicing: {self.slicing!r} (expected 'throughput' or 'latency')")
-        return self.slicing == "latency"
+        return 0 if self.slicing != "latency" else (2 if N <= 8 else 1)
 
     # ------------------------------------------------------------------ reference API
     def forward(self, x: Tensor, condition: Tensor, feature_condition: Tensor = None, t: Optional[Tensor] = None,

@@ -24,7 +24,7 @@ extern "C" {
 
 #define CCDM_ABI_VERSION 4
 #define CCDM_MAX_CHANNELS 1024      /* max C0+C1 of a GroupNorm'ed conv input */
-#define CCDM_STATS_MAX_SLICES 32    /* partial-statistics slices per sample a GroupNorm consumer reads (more: ccdm_stats_fold) */
+#define CCDM_STATS_MAX_SLICES 64    /* partial-statistics slices per sample a GroupNorm consumer reads (more: ccdm_stats_fold) */
 #define CCDM_STATS_FOLD_SLICES 16   /* what ccdm_stats_fold reduces a larger slice count to */
 
 int ccdm_version(void);
@@ -86,7 +86,7 @@ typedef struct ccdm_conv_args {
      * Requires stride 1, up 0, skip tensors [N,Hout,Wout,SC*].  skip0 == NULL: none. */
     const float* skip0; const float* skip1; int32_t SC0; int32_t SC1;
     const void* skip_w;
-    /* 1: latency slicing — more, shorter workgroups per sample (ccdm_conv_slices_ex(..., fine = 1): up to 32 slices where the
+    /* 1 / 2: latency slicing — more, shorter workgroups per sample (ccdm_conv_slices_ex(..., fine): up to 32 / 64 slices where the
      * default rule gives fewer, e.g. 32 instead of 12 at 128x128; 32x32 images on 8x16 tiles, 16x16 on 8x8) for batches too small to fill the chip.  The
      * statistics partials — and with them the last bit of a GroupNorm — depend on the slice count, so a run is bit-reproducible
      * across batch shardings only within one slicing mode; 0 (default) is the batch-size-independent rule. */

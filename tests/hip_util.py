@@ -70,7 +70,7 @@ def conv2d(srcs, weight, bias, ksize, *, stats=None, gamma=None, beta=None, act=
         args.gamma, args.beta = g.data_ptr(), bt.data_ptr()
     args.eps, args.act = 1e-5, act
     args.N, args.Hin, args.Win, args.Hout, args.Wout = N, Hin, Win, Hout, Wout
-    args.ksize, args.stride, args.up, args.fine_slices = ksize, stride, int(up), int(fine)
+    args.ksize, args.stride, args.up, args.fine_slices = ksize, stride, int(up), int(fine)      # fine: False / True (level 1) / 2
     args.w, args.bias, args.Cout, args.prec = wdev.data_ptr(), bdev.data_ptr(), cout, prec
     args.emb_off = -1
     table = emb if emb is not None else film

@@ -170,6 +170,15 @@ def test_conv_latency_slicing(U, c0, cout, H, W, k, stride, up):
     lib = hip.load()
     base, st0 = U.conv2d([xs], w.numpy(), b.numpy(), k, stride=stride, up=up, prec=hip.PREC_F16X3)
     fine, st1 = U.conv2d([xs], w.numpy(), b.numpy(), k, stride=stride, up=up, prec=hip.PREC_F16X3, fine=True)
+    if (H, W, stride, up) == (128, 128, 1, 0):      # level 2 (batches of <= 8): one tile per workgroup, 64 partials read in one prefetch round
+        f2, st2 = U.conv2d([xs], w.numpy(), b.numpy(), k, stride=stride, up=up, prec=hip.PREC_F16X3, fine=2)
+        assert torch.equal(base, f2) and st2.shape[1] == 64
+        np.testing.assert_allclose(st2.sum(1).cpu().numpy(), st0.sum(1).cpu().numpy(), rtol=1e-6, atol=1e-3)
+        g2, be2 = 1 + rnd(rng, cout, scale=0.1), rnd(rng, cout, scale=0.1)
+        w3 = rnd(rng, 32, cout, 3, 3) / np.sqrt(cout * 9)
+        ya, _ = U.conv2d([base], w3.numpy(), np.zeros(32, np.float32), 3, stats=[st0], gamma=g2.numpy(), beta=be2.numpy(), act=hip.ACT_SILU, prec=hip.PREC_F16X3)
+        yb, _ = U.conv2d([f2], w3.numpy(), np.zeros(32, np.float32), 3, stats=[st2], gamma=g2.numpy(), beta=be2.numpy(), act=hip.ACT_SILU, prec=hip.PREC_F16X3, fine=2)
+        np.testing.assert_allclose(yb.cpu().numpy(), ya.cpu().numpy(), rtol=0, atol=2e-6)
     if (H, W, k) == (16, 16, 3):
         # latency slicing also re-tiles 16x16 images (8x8 tiles, kernel rows split over three wave groups): another summation order
         np.testing.assert_allclose(fine.cpu().numpy(), base.cpu().numpy(), rtol=0, atol=4e-6)

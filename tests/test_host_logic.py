@@ -81,6 +81,7 @@ def test_pack_conv_weight_layout():
     lib = hip.load()
     # ccdm_conv_slices_ex: from the INPUT geometry; fine = the latency slicing (up to 32 slices where the default gives fewer)
     assert lib.ccdm_conv_slices_ex(128, 128, 3, 1, 0, 0) == 12 and lib.ccdm_conv_slices_ex(128, 128, 3, 1, 0, 1) == 32
+    assert lib.ccdm_conv_slices_ex(128, 128, 3, 1, 0, 2) == 64 and lib.ccdm_conv_slices_ex(64, 64, 3, 1, 0, 2) == 16
     assert lib.ccdm_conv_slices_ex(128, 128, 3, 2, 0, 0) == lib.ccdm_conv_slices(64, 64, 2, 3)
     assert lib.ccdm_conv_slices_ex(64, 64, 3, 1, 0, 1) == 16 and lib.ccdm_conv_slices_ex(8, 8, 3, 1, 0, 1) == 1
     assert lib.ccdm_conv_slices_ex(64, 64, 3, 1, 2, 0) == lib.ccdm_upconv_slices(64, 64) == 8 and lib.ccdm_conv_slices_ex(64, 64, 3, 1, 2, 1) == 32
