@@ -170,9 +170,13 @@ __device__ __forceinline__ const char* gn_channel_row(const ccdm_conv_args& a, i
 // threads at the full-resolution stages), so the first G * C threads each take 16 slices of one channel: up to 64 slices are summed
 // from ONE prefetch round.  G = min(NT / C, 4); threads beyond G * C idle (their loads are clamped duplicates).
 struct GnLane { int c, grp, G; };
-__device__ __forceinline__ GnLane gn_lane(int C, int tid, int NT) {
+__device__ __forceinline__ GnLane gn_lane(const ccdm_conv_args& a, int tid, int NT) {
+    const int C = a.C0 + a.C1;
+    const int smax = a.slices0 > a.slices1 ? a.slices0 : a.slices1;
+    const int need = smax > 16 ? (smax + 15) >> 4 : 1;                   // slot groups the slice count asks for (1 wherever <= 16 slices)
     GnLane l;
     l.G = NT >= 4 * C ? 4 : (NT >= 3 * C ? 3 : (NT >= 2 * C ? 2 : 1));
+    l.G = l.G < need ? l.G : need;
     l.grp = (tid >= C ? 1 : 0) + (tid >= 2 * C ? 1 : 0) + (tid >= 3 * C ? 1 : 0);
     l.c = tid - l.grp * C;
     if (l.grp >= l.G || l.c >= C) { l.grp = l.G; l.c = C - 1; }         // idle lane (grp == G marks it)
@@ -180,7 +184,7 @@ __device__ __forceinline__ GnLane gn_lane(int C, int tid, int NT) {
 }
 __device__ __forceinline__ void gn_prefetch(const ccdm_conv_args& a, bool has_gn, int n, int emb_row, int tid, int NT, const void* dummy, GnPrefetch& g) {
     const int C = a.C0 + a.C1;
-    const GnLane l = gn_lane(C, tid, NT);
+    const GnLane l = gn_lane(a, tid, NT);
     const int c = l.c, grp = l.grp < l.G ? l.grp : l.G - 1;
     const float* df = static_cast<const float*>(dummy);
     const bool film = has_gn && a.film;
@@ -224,7 +228,7 @@ __device__ __forceinline__ f64x2 gn_channel_sums(const ccdm_conv_args& a, int n,
 __device__ __forceinline__ void gn_affine_block(const ccdm_conv_args& a, int n, int emb_row, const GnPrefetch& g, f64x2* scratch, float2* ab) {
     const int C = a.C0 + a.C1, cpg = C / 32;
     const int tid = threadIdx.x, NT = blockDim.x;
-    const GnLane l = gn_lane(C, tid, NT);
+    const GnLane l = gn_lane(a, tid, NT);
     const int G = l.G;
     auto group = [&](const int c) {
         const int c_lo = (c / cpg) * cpg;
