@@ -13,6 +13,7 @@
 // Precision: every product is the 3-term fp16 hi/lo split (lo*hi + hi*lo + hi*hi, fp32 accumulate, ~2^-22) used by
 // the convs; P in [0,1] needs no scaling.  exp is v_exp_f32.
 #include "ccdm_common.h"
+#include <cstdlib>
 #include "ccdm_conv_common.h"
 
 namespace ccdm {
@@ -231,14 +232,19 @@ __global__ __launch_bounds__(WAVES * 64) void k_attention_mfma(const float* __re
 
 int launch_attention_mfma(const float* qkv, float* out, int N, int T, int Ta, int C, int heads, int order, hipStream_t s) {
     const int D = C / heads;
-    const int waves = T >= 128 ? 4 : (T >= 64 ? 2 : 1);
+    // 8 waves (256 queries) per block for long sequences at head width 32: a key tile's staging (split to fp16 hi/lo, LDS writes) is
+    // shared by twice as many queries — one item per thread instead of two
+    // (T = 8192, N = 4, 4 heads: 570 -> 502 us = 29.0 -> 32.8 % of the fp16 matrix peak by instruction count; T = 2048: 90 -> 83 us)
+    static const int w8_min = getenv("CCDM_ATTN_W8_MIN") ? atoi(getenv("CCDM_ATTN_W8_MIN")) : 2048;      // A/B hook (0: never)
+    const int waves = (D == 32 && w8_min > 0 && T >= w8_min) ? 8 : (T >= 128 ? 4 : (T >= 64 ? 2 : 1));
     dim3 grid(cdiv(T, 32 * waves), heads, N);
     if (D == 64) {
         if (waves == 4) hipLaunchKernelGGL((k_attention_mfma<4, 64>), grid, dim3(256), 0, s, qkv, out, T, Ta, C, order);
         else if (waves == 2) hipLaunchKernelGGL((k_attention_mfma<2, 64>), grid, dim3(128), 0, s, qkv, out, T, Ta, C, order);
         else hipLaunchKernelGGL((k_attention_mfma<1, 64>), grid, dim3(64), 0, s, qkv, out, T, Ta, C, order);
     } else {
-        if (waves == 4) hipLaunchKernelGGL((k_attention_mfma<4, 32>), grid, dim3(256), 0, s, qkv, out, T, Ta, C, order);
+        if (waves == 8) hipLaunchKernelGGL((k_attention_mfma<8, 32>), grid, dim3(512), 0, s, qkv, out, T, Ta, C, order);
+        else if (waves == 4) hipLaunchKernelGGL((k_attention_mfma<4, 32>), grid, dim3(256), 0, s, qkv, out, T, Ta, C, order);
         else if (waves == 2) hipLaunchKernelGGL((k_attention_mfma<2, 32>), grid, dim3(128), 0, s, qkv, out, T, Ta, C, order);
         else hipLaunchKernelGGL((k_attention_mfma<1, 32>), grid, dim3(64), 0, s, qkv, out, T, Ta, C, order);
     }

@@ -1444,7 +1444,8 @@ def test_attention_stress_mfma_vs_valu(U, parity_log):
     import os
     lib = hip.load()
     cases = [(3, 256, 256, 96, 3, 0), (5, 64, 64, 128, 4, 1), (2, 2048, 2048, 64, 2, 0), (1, 8192, 8192, 128, 4, 0),
-             (3, 2049, 2064, 384, 6, 1), (2, 197, 208, 384, 6, 1), (4, 512, 512, 128, 4, 0), (2, 33, 48, 128, 2, 1)]
+             (3, 2049, 2064, 384, 6, 1), (2, 197, 208, 384, 6, 1), (4, 512, 512, 128, 4, 0), (2, 33, 48, 128, 2, 1),
+             (2, 2100, 2112, 64, 2, 1)]          # (head width 32 from T = 2048 on: 8-wave blocks of 256 queries; ragged last block)
     iters = int(os.environ.get("CCDM_STRESS_ITERS", "1000")) // len(cases)
     worst = 0.0
     for (N, T, Ta, C, heads, order) in cases:
