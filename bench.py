@@ -62,11 +62,30 @@ def cpu_model_name() -> str:
     return "unknown"
 
 
-def cpu_baseline(sd, image4, cfg, seed=0):
-    """Oracle (CPU restatement of the reference, torch-CPU fp32) on a bounded sample of the same workload:
-    N=4, the first few of T denoise steps (about 15 s of CPU work), extrapolated to T."""
+def _cpu_probe_child(threads: int, n_steps: int, cfg_name: str) -> None:
+    """child process of cpu_baseline's all-cores probe: time n_steps oracle denoise steps at N=4 with `threads` threads"""
+    from ccdm_stochastic_segmentation_amd import build_model, make_synthetic_state_dict
     from oracle import ccdm_oracle as O
-    # more threads than ~16 makes torch-CPU slower on these small convs (256-core host: 85 s per step)
+    cfg = CONFIGS[cfg_name]
+    T, K, H, W, C_img = cfg["T"], cfg["K"], cfg["H"], cfg["W"], cfg["C_img"]
+    model = build_model(T, "cosine", {"s": 0.008}, [(C_img, H, W), (K, H, W)], (C_img, H, W), "unet_openai", cfg["bp"], "datasets.lidc", "confidence", cfg["fce"])
+    sd = {k: torch.from_numpy(v) for k, v in make_synthetic_state_dict(model.unet.spec, 0).items()}
+    torch.set_num_threads(threads)
+    image4 = torch.from_numpy(np.random.default_rng(1234).uniform(-1, 1, (4, C_img, H, W)).astype(np.float32))
+    sched = O.make_schedule("cosine", T, {"s": 0.008})
+    torch.manual_seed(0)
+    idx, _ = O.draw_x_T(4, K, H, W)
+    x = O.one_hot_bchw(idx, K)
+    t0 = time.perf_counter()
+    O.forward_denoising(sd, dict(num_heads=1, num_head_channels=32), sched, x, image4, None, n_steps, "confidence")
+    print(json.dumps({"ms_per_denoise_step_n4": (time.perf_counter() - t0) / n_steps * 1e3, "threads": torch.get_num_threads()}))
+
+
+def cpu_baseline(sd, image4, cfg, cfg_name, seed=0, budget_s=30.0):
+    """Oracle (CPU restatement of the reference, torch-CPU fp32) on the same workload at N=4: ONE FULL T-step sampling
+    run when it fits the budget (T=250 takes 15-30 s on the GPU box's host), else the first steps extrapolated; at <= 16 threads (more
+    threads make torch-CPU slower on these small convs) — plus a bounded probe at os.cpu_count() threads in a child process."""
+    from oracle import ccdm_oracle as O
     torch.set_num_threads(min(os.cpu_count() or 1, 16))
     T, K, H, W = cfg["T"], cfg["K"], cfg["H"], cfg["W"]
     sched = O.make_schedule("cosine", T, {"s": 0.008})
@@ -75,21 +94,38 @@ def cpu_baseline(sd, image4, cfg, seed=0):
     x = O.one_hot_bchw(idx, K)
     ocfg = dict(num_heads=1, num_head_channels=32)
     t0 = time.perf_counter()
-    O.forward_denoising(sd, ocfg, sched, x, image4, None, 1, "confidence")            # warm-up: 1 step
-    warm = time.perf_counter() - t0
-    n_steps = int(max(2, min(T, 15.0 / max(warm, 1e-3))))
+    O.forward_denoising(sd, ocfg, sched, x, image4, None, 2, "confidence")            # warm-up: 2 steps
+    warm = (time.perf_counter() - t0) / 2
+    full = warm * T <= budget_s
+    n_steps = T if full else int(max(2, min(T, 15.0 / max(warm, 1e-3))))
     t0 = time.perf_counter()
-    O.forward_denoising(sd, ocfg, sched, x, image4, None, n_steps, "confidence")
+    O.forward_denoising(sd, ocfg, sched, x, image4, None, None if full else n_steps, "confidence")
     dt = time.perf_counter() - t0
     ms_step = dt / n_steps * 1e3
     v = 4.0 / (ms_step * 1e-3 * T)
-    return {"value": v, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle (torch-CPU fp32, {torch.get_num_threads()} threads) N=4, {n_steps} of {T} denoise steps timed ({dt:.1f} s), extrapolated x{T}/{n_steps}",
-            "ms_per_denoise_step_n4": ms_step, "host_cpu": cpu_model_name(), "host_logical_cpus": os.cpu_count(),
-            "oracle_over_reference_time": ORACLE_OVER_REFERENCE_TIME,
-            "value_reference_equivalent": v * ORACLE_OVER_REFERENCE_TIME,
-            "note": "the oracle is 14.8 % slower than the real reference on identical inputs (build-container measurement, outputs bit-identical): "
-                    "value_reference_equivalent is the estimate for the reference itself on this host"}
+    res = {"value": v, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": (f"oracle (torch-CPU fp32, {torch.get_num_threads()} threads) N=4, one FULL run of all {T} denoise steps timed ({dt:.1f} s)" if full else
+                      f"oracle (torch-CPU fp32, {torch.get_num_threads()} threads) N=4, {n_steps} of {T} denoise steps timed ({dt:.1f} s), extrapolated x{T}/{n_steps}"),
+           "full_run": bool(full), "ms_per_denoise_step_n4": ms_step, "host_cpu": cpu_model_name(), "host_logical_cpus": os.cpu_count(),
+           "oracle_over_reference_time": ORACLE_OVER_REFERENCE_TIME, "value_reference_equivalent": v * ORACLE_OVER_REFERENCE_TIME,
+           "note": "oracle_over_reference_time is the build-container measurement of the oracle against the real reference on identical inputs "
+                   "(tools/time_reference_cpu.py, outputs bit-identical); value_reference_equivalent is the estimate for the reference itself on this host"}
+    # all logical CPUs (BASELINE.md §3 asks for the figure): one denoise step in a child process, bounded — on a 256-thread host torch-CPU
+    # needs over a minute per step for these small convs
+    ncpu = os.cpu_count() or 1
+    if ncpu > torch.get_num_threads():
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-probe", str(ncpu), "--config", cfg_name], capture_output=True, text=True,
+                               timeout=25, env=dict(os.environ, CCDM_BENCH_CHILD="1"))
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            res["all_cores"] = {"cores": d["threads"], "ms_per_denoise_step_n4": d["ms_per_denoise_step_n4"],
+                                "value": 4.0 / (d["ms_per_denoise_step_n4"] * 1e-3 * T), "sample": "1 denoise step at N=4, extrapolated"}
+        except subprocess.TimeoutExpired:
+            res["all_cores"] = {"cores": ncpu, "value": None, "sample": "1 denoise step at N=4 did not finish within 25 s (> 6 s per sample-step): "
+                                                                        "slower than the 16-thread figure by more than 10x"}
+        except Exception as e:       # noqa: BLE001
+            res["all_cores"] = {"cores": ncpu, "value": None, "sample": f"probe failed: {e}"}
+    return res
 
 
 def self_launch(args) -> int:
@@ -114,14 +150,13 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2",
                     help="workload (BASELINE.json configs); the headline metric is quoted on c2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the untimed extras (per-stage table, --substreams 2 figure)")
-    ap.add_argument("--graph", type=int, default=0, help="1: replay each denoise step as a HIP graph (no kernel taps)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the untimed extras (roofline taps, per-stage table, single-stream figure)")
+    ap.add_argument("--graph", type=int, default=-1, help="1 / 0: replay each denoise step as a HIP graph / launch eagerly (default: the product default, graph)")
     ap.add_argument("--batch", type=int, default=0, help="samples per GPU (default: the config's)")
     ap.add_argument("--denoise-steps", type=int, default=0, help="strided walk of this many denoise steps instead of the full T (diagnostics; not the metric)")
-    ap.add_argument("--substreams", type=int, default=1,
+    ap.add_argument("--substreams", type=int, default=-1,
                     help="sample the per-GPU batch as this many contiguous sub-batches on concurrent HIP streams (results are bit-identical); "
-                         "0 = automatic (two from 32 samples up).  Default 1 = DenoisingModel's default: kernels run alone, so the HIP-event "
-                         "taps describe the kernels; the 2-stream figure is reported as `substreams2`")
+                         "0 = automatic (two from 32 samples up).  Default: the product default (automatic)")
     ap.add_argument("--rng", choices=["philox", "torch_cpu"], default="philox",
                     help="philox: noise generated in the epilogue kernel (the benchmark); torch_cpu: the parity mode — Exp(1) noise drawn "
                          "on the host in the reference's order and copied over PCIe (host-RNG bound; reported for DESIGN.md, never the headline)")
@@ -129,14 +164,18 @@ def main():
                     help="conv arithmetic: exact fp32 MFMA, or fp16 hi/lo split x3 MFMA with fp32 accumulate (~2^-22)")
     ap.add_argument("--slicing", default="throughput", choices=["throughput", "latency"],
                     help="DenoisingModel.slicing: 'latency' = more, shorter conv workgroups per sample (small batches)")
-    ap.add_argument("--per-op", default="", help="write the per-op table of one extra tapped pass to this file (JSON)")
+    ap.add_argument("--per-op", default="", help="write the per-op table of the tapped pass to this file (JSON)")
+    ap.add_argument("--cpu-probe", type=int, default=0, help=argparse.SUPPRESS)      # child mode of cpu_baseline's all-cores probe
     args = ap.parse_args()
+    if args.cpu_probe:
+        _cpu_probe_child(args.cpu_probe, 1, args.config)
+        return
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         raise SystemExit(self_launch(args))
 
     from ccdm_stochastic_segmentation_amd import build_model, make_synthetic_state_dict, hip
-    from ccdm_stochastic_segmentation_amd.distributed import init_from_env, all_gather_ragged
+    from ccdm_stochastic_segmentation_amd.distributed import init_from_env, all_gather_shards
     import torch.distributed as dist
 
     rank, local_rank, world = init_from_env()
@@ -156,10 +195,17 @@ def main():
     model = model.to(dev).eval()
     f16 = args.prec == "f16x3"
     model.prec = hip.PREC_F16X3 if f16 else hip.PREC_F32
-    model.rng, model.philox_seed, model.use_graph = args.rng, 2024, bool(args.graph)
+    model.rng, model.philox_seed = args.rng, 2024
+    # the timed configuration is the product default (DenoisingModel: HIP-graph replay, automatic sub-batching) unless overridden
+    if args.graph >= 0:
+        model.use_graph = bool(args.graph)
+    if args.substreams >= 0:
+        model.substreams = args.substreams
     model.sample_offset = rank * n                                # Philox counters keyed by global sample index
-    model.substreams = args.substreams
     model.slicing = args.slicing
+    use_graph, substreams = bool(model.use_graph), int(model.substreams)
+    nsub = substreams if substreams > 0 else (2 if n >= 32 else 1)
+    nsub = max(1, min(nsub, n))
 
     rng = np.random.default_rng(1234)
     if cfg["image"] == "uniform":
@@ -174,65 +220,44 @@ def main():
     x = x.permute(0, 3, 1, 2).float().to(dev)
     t_arg = {} if not args.denoise_steps else {"t": torch.as_tensor(10000 + args.denoise_steps)}
     n_dsteps = args.denoise_steps or T
+    gather_buf = [None]
+    t_sample, t_gather = [0.0], [0.0]
 
-    def one_pass():
+    def one_pass(timed=False):
         out = model(x, image, feat, **t_arg)["diffusion_out"]
         if world > 1:
-            out = all_gather_ragged(out.contiguous(), n * world, world)     # the path's only collective
+            if timed:                                             # per-rank split of the pass: sampling vs. the path's only collective
+                torch.cuda.synchronize()
+                t_a = time.perf_counter()
+            out, gather_buf[0] = all_gather_shards(out.contiguous(), n * world, world, gather_buf[0])
+            if timed:
+                torch.cuda.synchronize()
+                t_gather[0] += time.perf_counter() - t_a
         return out
 
     for _ in range(args.warmup):
         one_pass()
-    # the executor of sub-batch 0 (the whole batch when substreams == 1) carries the HIP-event taps
-    nsub = args.substreams if args.substreams > 0 else (2 if n >= 32 else 1)
-    nsub = max(1, min(nsub, n))
-    n_tap = n // nsub
-    eng = model._engine(x[:n_tap], image[:n_tap], feat[:n_tap] if feat is not None else None, slot=0)
-    # The dominant kernel = the conv instantiation of the full-resolution stage: every 3x3 stride-1 conv whose output is HxW runs
-    # the same k_conv<...> symbol on the same grid (C2: 9 launches per denoise step, 28 % of its time) — the unit rocprofv3's
-    # per-kernel statistics report.  All of its launches are tapped; `roofline` is their aggregate (sum of algorithmic bytes
-    # over sum of durations), `roofline_shapes` splits it by layer shape.
-    info = eng.op_info
-    # (the Upsample conv that lands on HxW runs the sub-pixel instantiation k_conv<...,UP2> on the low-resolution grid, the convs with a fused
-    #  1x1 skip of 32-channel sources the core-only skip-chunk instantiation k_conv<...,SKWT>: other symbols — they appear in roofline_shapes
-    #  of the per-op pass and in the per-op table, not in this class)
-    dom_ops = [i for i, o in enumerate(info) if o["kind"] == "conv" and o["k"] == 3 and o["stride"] == 1 and (o["hout"], o["wout"]) == (H, W)
-               and not o.get("subpixel") and not o.get("skip_wide")]
-    attn_ops = [i for i, o in enumerate(info) if o["kind"] == "attention" and o["T"] >= 2048]
-    attn = max(attn_ops, key=lambda i: info[i]["T"]) if attn_ops else None
-    taps = not args.graph
-    tapped = dom_ops + ([attn] if attn is not None else [])
-    if taps:
-        for i in tapped:
-            eng.profile_op(i, capacity=n_dsteps)          # HIP events around that launch, on the engine's stream
 
+    # ---- the timed region: exactly `steps` passes of the product path; no taps, no host synchronisation between passes (N = 1) ----
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    kern = {i: [] for i in tapped}
-    info = eng.op_info
     for _ in range(args.steps):
-        out = one_pass()
-        if taps:
-            torch.cuda.synchronize()
-            for i in tapped:
-                kern[i].append(eng.profile_read(i))
+        out = one_pass(timed=world > 1)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    per_rank = None
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        mine = torch.tensor([dt, t_gather[0]], device=dev, dtype=torch.float64)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": r, "pass_s": float(v[0]) / max(args.steps, 1), "sampling_s": float(v[0] - v[1]) / max(args.steps, 1),
+                     "gather_s": float(v[1]) / max(args.steps, 1)} for r, v in enumerate(allr)]
+        dt = max(float(v[0]) for v in allr)
     assert torch.isfinite(out).all()
-    if taps:
-        eng.profile_op(-1)
-
-    def mean_ms(i):
-        cnt = sum(k_[0] for k_ in kern[i])
-        return (sum(k_[0] * k_[1] for k_ in kern[i]) / cnt, cnt) if cnt else (0.0, 0)
 
     res = None
     if rank == 0:
@@ -247,110 +272,126 @@ def main():
             "config": {"workload": f"{cfg['title']}, batch={n} per GPU, "
                                    f"{'device Philox RNG' if args.rng == 'philox' else 'host torch-CPU Exp(1) noise over PCIe (parity mode)'}, random-init weights",
                        "name": args.config, "global_batch": n * world, "time_steps": T, "denoise_steps_run": n_dsteps,
-                       "parallelism": f"batch-shard x{world}", "launch": "hip-graph" if args.graph else "eager", "substreams": nsub,
+                       "parallelism": f"batch-shard x{world}", "launch": "hip-graph" if use_graph else "eager", "substreams": nsub,
                        "slicing": args.slicing},
         }
+        if per_rank is not None:
+            res["per_rank"] = per_rank
         step_bytes = (cfg["algo_mb"] * n + cfg["weights_mb"]) * 1e6
         fr = step_bytes / (ms_dstep * 1e-3) / 1e9
         res["roofline_step"] = {"bound": "hbm", "achieved": fr, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fr / HBM_PEAK_GBS,
-                                "note": f"whole denoise step per GPU: SURVEY 8(d) {cfg['algo_mb']} MB/sample + {cfg['weights_mb']} MB weights, over ms_per_denoise_step",
+                                "note": f"whole denoise step per GPU in the TIMED region: SURVEY 8(d) {cfg['algo_mb']} MB/sample + {cfg['weights_mb']} MB weights, over ms_per_denoise_step",
                                 "algorithmic_tflops": cfg["gflop"] * n / ms_dstep, "mfma_util": (3.0 if f16 else 16.0) * cfg["gflop"] * n / ms_dstep / MFMA_PEAK_TFLOPS}
         res["roofline"] = None
-        if taps:
-            per = {i: mean_ms(i) for i in dom_ops}
-            if all(c for _, c in per.values()):
-                tot_ms = sum(m for m, _ in per.values())
-                bytes_all = sum(info[i]["io_bytes"] * n_tap + info[i]["gn_read_bytes"] * n_tap + info[i]["weight_bytes"] for i in dom_ops)
-                bytes_io = sum(info[i]["io_bytes"] * n_tap + info[i]["weight_bytes"] for i in dom_ops)
-                flop = sum(info[i]["flop"] * n_tap for i in dom_ops)
-                ach = bytes_all / (tot_ms * 1e-3) / 1e9
-                shapes = {}
-                for i in dom_ops:
-                    o = info[i]
-                    key = f"{o['cin']}->{o['cout']}" + (" +fused 1x1 skip" if o["skip"] else "") + (" up2x" if o["up"] else "") + ("" if o["gn"] else " (no GroupNorm)")
-                    sh = shapes.setdefault(key, dict(launches_per_denoise_step=0, ms=0.0, bytes=0, bytes_io=0, flop=0, ops=[]))
-                    sh["launches_per_denoise_step"] += 1
-                    sh["ms"] += per[i][0]
-                    sh["bytes"] += o["io_bytes"] * n_tap + o["gn_read_bytes"] * n_tap + o["weight_bytes"]
-                    sh["bytes_io"] += o["io_bytes"] * n_tap + o["weight_bytes"]
-                    sh["flop"] += o["flop"] * n_tap
-                    sh["ops"].append(i)
-                res["roofline"] = {
-                    "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                    "traffic": None, "traffic_source": "PMC passes are collected off-line (profiles/): HBM counters cannot be read inside the timed run",
-                    "kernel": f"ccdm::k_conv<F16X3,16,3,1,8,32,4,2,1,1> (<PREC,CK,KS,STRIDE,TH,TW,WAVES,MI,NI,KSP>): every 3x3 stride-1 conv of the {H}x{W} stage "
-                              f"(engine ops {dom_ops}), GN+SiLU on load" if f16 else f"ccdm::k_conv<F32,...> every 3x3 stride-1 conv of the {H}x{W} stage (engine ops {dom_ops})",
-                    "launches_per_denoise_step": len(dom_ops), "avg_launch_ms": tot_ms / len(dom_ops), "launches_timed": sum(c for _, c in per.values()),
-                    "algorithmic_bytes_per_launch": bytes_all / len(dom_ops), "samples_per_launch": n_tap, "concurrent_streams": nsub,
-                    "achieved_conv_io_only": bytes_io / (tot_ms * 1e-3) / 1e9, "frac_conv_io_only": bytes_io / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    "share_of_denoise_step": tot_ms / ms_dstep,
-                    "algorithmic_tflops": flop / (tot_ms * 1e-3) / 1e12,
-                    # matrix-pipe utilisation from the instruction count: every fp32 product is 3 fp16 MFMA products (hi*hi, hi*lo, lo*hi);
-                    # relative to the dense fp16 peak at the top clock (the PMC figure SQ_VALU_MFMA_BUSY_CYCLES is in profiles/)
-                    "mfma_util": (3.0 if f16 else 16.0) * flop / (tot_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
-                    "mfma_util_source": "analytic: MFMA FLOPs issued (3 fp16 products per fp32 product) / HIP-event duration / 2.5 PFLOP/s dense",
-                }
-                res["roofline_shapes"] = {
-                    k_: {"launches_per_denoise_step": v["launches_per_denoise_step"], "avg_launch_ms": v["ms"] / v["launches_per_denoise_step"],
-                         "frac": v["bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "frac_conv_io_only": v["bytes_io"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "mfma_util": (3.0 if f16 else 16.0) * v["flop"] / (v["ms"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "engine_ops": v["ops"]}
-                    for k_, v in shapes.items()}
-            if attn is not None:
-                m_a, c_a = mean_ms(attn)
-                if c_a:
-                    o = info[attn]
-                    fl = o["flop"] * n_tap
-                    res["roofline_attention"] = {
-                        "bound": "mfma", "achieved": fl / (m_a * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": fl / (m_a * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "mfma_util": 3.0 * fl / (m_a * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
-                        "avg_launch_ms": m_a, "launches_timed": c_a, "traffic": None,
-                        "kernel": f"ccdm::k_attention_mfma (engine op {attn}, {eng.op_names[attn]}: T={o['T']}, C={o['C']}, {o['heads']} heads of {o['C'] // o['heads']})",
-                        "note": "frac = algorithmic FLOPs (4*T*T*C per sample) over the dense fp16 MFMA peak; mfma_util counts the 3 fp16 MFMAs each product is made of"}
 
-    # ---- untimed extras (rank 0, single GPU): per-stage split of one tapped pass, the two-stream figure ----
-    if world == 1 and not args.no_secondary and taps and nsub == 1:
-        for i in range(len(eng.op_info)):
+    # ---- untimed, rank 0 at N = 1: ONE single-stream eager pass with HIP-event taps on every op (on the engine's stream) -> the dominant
+    #      kernel's roofline, the per-stage split, the per-op table; then the single-stream figure of the same product path ----
+    if world == 1 and not args.no_secondary:
+        model.substreams, model.use_graph = 1, False
+        one_pass()                                                 # builds the whole-batch executor
+        torch.cuda.synchronize()
+        eng = model._engine(x, image, feat, slot=0)
+        info = eng.op_info
+        # The dominant kernel = the conv instantiation of the full-resolution stage: every 3x3 stride-1 conv whose output is HxW runs
+        # the same k_conv<...> symbol on the same grid (C2: 9 launches per denoise step) — the unit rocprofv3's per-kernel statistics
+        # report.  (The Upsample conv that lands on HxW runs the sub-pixel instantiation, the convs with a fused 1x1 skip of 32-channel
+        # sources the core-only skip-chunk instantiation: other symbols — in the per-op table, not in this class.)
+        dom_ops = [i for i, o in enumerate(info) if o["kind"] == "conv" and o["k"] == 3 and o["stride"] == 1 and (o["hout"], o["wout"]) == (H, W)
+                   and not o.get("subpixel") and not o.get("skip_wide")]
+        attn_ops = [i for i, o in enumerate(info) if o["kind"] == "attention" and o["T"] >= 2048]
+        attn = max(attn_ops, key=lambda i: info[i]["T"]) if attn_ops else None
+        for i in range(len(info)):
             eng.profile_op(i, capacity=n_dsteps)
         one_pass()
         torch.cuda.synchronize()
+        taps = [eng.profile_read(i) for i in range(len(info))]       # (launches, mean ms, min ms, max ms)
+        eng.profile_op(-1)
+        tap_note = (f"HIP events on the engine's stream around every launch of one extra UNTIMED pass of the same workload on ONE stream, eager launches "
+                    f"({n_dsteps} denoise steps); the timed region runs {nsub} concurrent sub-batch stream(s) "
+                    f"{'as HIP-graph replays' if use_graph else 'eagerly'} without taps — under concurrency a launch's event duration no longer describes the kernel")
+        if dom_ops and all(taps[i][0] for i in dom_ops):
+            tot_ms = sum(taps[i][1] for i in dom_ops)
+            bytes_all = sum(info[i]["io_bytes"] * n + info[i]["gn_read_bytes"] * n + info[i]["weight_bytes"] for i in dom_ops)
+            bytes_io = sum(info[i]["io_bytes"] * n + info[i]["weight_bytes"] for i in dom_ops)
+            flop = sum(info[i]["flop"] * n for i in dom_ops)
+            ach = bytes_all / (tot_ms * 1e-3) / 1e9
+            step_ms_tapped = sum(t_[1] for t_ in taps)
+            shapes = {}
+            for i in dom_ops:
+                o = info[i]
+                key = f"{o['cin']}->{o['cout']}" + (" +fused 1x1 skip" if o["skip"] else "") + (" up2x" if o["up"] else "") + ("" if o["gn"] else " (no GroupNorm)")
+                sh = shapes.setdefault(key, dict(launches_per_denoise_step=0, ms=0.0, bytes=0, bytes_io=0, flop=0, ops=[]))
+                sh["launches_per_denoise_step"] += 1
+                sh["ms"] += taps[i][1]
+                sh["bytes"] += o["io_bytes"] * n + o["gn_read_bytes"] * n + o["weight_bytes"]
+                sh["bytes_io"] += o["io_bytes"] * n + o["weight_bytes"]
+                sh["flop"] += o["flop"] * n
+                sh["ops"].append(i)
+            res["roofline"] = {
+                "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": None, "traffic_source": "PMC passes are collected off-line (profiles/): HBM counters cannot be read inside the bench run",
+                "note": tap_note,
+                "kernel": f"ccdm::k_conv<F16X3,16,3,1,8,32,4,2,1,1> (<PREC,CK,KS,STRIDE,TH,TW,WAVES,MI,NI,KSP>): every 3x3 stride-1 conv of the {H}x{W} stage "
+                          f"(engine ops {dom_ops}), GN+SiLU on load" if f16 else f"ccdm::k_conv<F32,...> every 3x3 stride-1 conv of the {H}x{W} stage (engine ops {dom_ops})",
+                "launches_per_denoise_step": len(dom_ops), "avg_launch_ms": tot_ms / len(dom_ops), "launches_timed": sum(taps[i][0] for i in dom_ops),
+                "algorithmic_bytes_per_launch": bytes_all / len(dom_ops), "samples_per_launch": n, "concurrent_streams": 1,
+                "achieved_conv_io_only": bytes_io / (tot_ms * 1e-3) / 1e9, "frac_conv_io_only": bytes_io / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "share_of_denoise_step": tot_ms / max(step_ms_tapped, 1e-9),
+                "algorithmic_tflops": flop / (tot_ms * 1e-3) / 1e12,
+                # matrix-pipe utilisation from the instruction count: every fp32 product is 3 fp16 MFMA products (hi*hi, hi*lo, lo*hi);
+                # relative to the dense fp16 peak at the top clock (the PMC figure SQ_VALU_MFMA_BUSY_CYCLES is in profiles/)
+                "mfma_util": (3.0 if f16 else 16.0) * flop / (tot_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
+                "mfma_util_source": "analytic: MFMA FLOPs issued (3 fp16 products per fp32 product) / HIP-event duration / 2.5 PFLOP/s dense",
+            }
+            res["roofline_shapes"] = {
+                k_: {"launches_per_denoise_step": v["launches_per_denoise_step"], "avg_launch_ms": v["ms"] / v["launches_per_denoise_step"],
+                     "frac": v["bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "frac_conv_io_only": v["bytes_io"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "mfma_util": (3.0 if f16 else 16.0) * v["flop"] / (v["ms"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "engine_ops": v["ops"]}
+                for k_, v in shapes.items()}
+        if attn is not None and taps[attn][0]:
+            m_a, c_a = taps[attn][1], taps[attn][0]
+            o = info[attn]
+            fl = o["flop"] * n
+            res["roofline_attention"] = {
+                "bound": "mfma", "achieved": fl / (m_a * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": fl / (m_a * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "mfma_util": 3.0 * fl / (m_a * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
+                "avg_launch_ms": m_a, "launches_timed": c_a, "traffic": None,
+                "kernel": f"ccdm::k_attention_mfma (engine op {attn}, {eng.op_names[attn]}: T={o['T']}, C={o['C']}, {o['heads']} heads of {o['C'] // o['heads']})",
+                "note": "frac = algorithmic FLOPs (4*T*T*C per sample) over the dense fp16 MFMA peak; mfma_util counts the 3 fp16 MFMAs each product is made of; " + tap_note}
         per_op = []
-        for i, o in enumerate(eng.op_info):
-            cnt, m, lo, hi = eng.profile_read(i)
+        for i, o in enumerate(info):
+            cnt, m, lo, hi = taps[i]
             per_op.append(dict(op=i, name=o["name"], kind=o["kind"], mean_us=m * 1e3, min_us=lo * 1e3, max_us=hi * 1e3,
                                shape=(f"{o['cin']}->{o['cout']} k{o['k']} @{o['hout']}x{o['wout']}" if o["kind"] == "conv" else
                                       (f"T={o['T']} C={o['C']}" if "T" in o else "")),
                                hbm_frac=(o["io_bytes"] * n + o["gn_read_bytes"] * n + o["weight_bytes"]) / max(m, 1e-9) / 1e6 / HBM_PEAK_GBS))
-        eng.profile_op(-1)
         by_stage = {}
         for p in per_op:
-            o = eng.op_info[p["op"]]
+            o = info[p["op"]]
             key = f"{o['hout']}x{o['wout']}" if o["kind"] == "conv" else o["kind"]
             by_stage[key] = by_stage.get(key, 0.0) + p["mean_us"]
         res["per_stage_us"] = {k_: round(v, 1) for k_, v in by_stage.items()}
-        res["per_stage_note"] = "sum of per-op mean launch times (HIP events around every op, one extra untimed pass) grouped by output size"
+        res["per_stage_note"] = "sum of per-op mean launch times of the tapped single-stream pass, grouped by output size"
         if args.per_op:
             with open(args.per_op, "w") as fh:
                 json.dump(per_op, fh, indent=1)
-        if args.rng == "philox" and n >= 2:
-            model.substreams = 2
-            one_pass()                                # builds the two half-batch executors
-            torch.cuda.synchronize()
-            reps = max(1, min(args.steps, 3))
-            t1 = time.perf_counter()
-            for _ in range(reps):
-                one_pass()
-            torch.cuda.synchronize()
-            dt2 = (time.perf_counter() - t1) / reps
-            step_bytes = (cfg["algo_mb"] * n + cfg["weights_mb"]) * 1e6
-            res["substreams2"] = {"value": n / dt2, "unit": "samples/s", "ms_per_denoise_step": dt2 / n_dsteps * 1e3,
-                                  "roofline_step_frac": step_bytes / (dt2 / n_dsteps) / 1e9 / HBM_PEAK_GBS, "passes": reps,
-                                  "note": "same workload walked as 2 concurrent sub-batches (DenoisingModel.substreams = 2; bit-identical samples): "
-                                          "secondary figure — under concurrency a launch's duration no longer describes the kernel, so the headline and "
-                                          "the roofline taps stay on one stream"}
-            model.substreams = args.substreams
+        # the same product path on ONE stream (graph replay as configured): what a kernel-by-kernel reading of the step adds up to
+        model.use_graph = use_graph
+        one_pass()
+        torch.cuda.synchronize()
+        reps = max(1, min(args.steps, 3))
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            one_pass()
+        torch.cuda.synchronize()
+        dt1 = (time.perf_counter() - t1) / reps
+        res["single_stream"] = {"value": n / dt1, "unit": "samples/s", "ms_per_denoise_step": dt1 / n_dsteps * 1e3,
+                                "roofline_step_frac": (cfg["algo_mb"] * n + cfg["weights_mb"]) * 1e6 / (dt1 / n_dsteps) / 1e9 / HBM_PEAK_GBS, "passes": reps,
+                                "note": "same workload on one stream (substreams = 1), same launch mode: secondary figure"}
+        model.substreams = substreams
     if rank == 0:
         if not args.no_cpu_baseline and world == 1 and args.config in ("c2", "c3shard"):
-            res["cpu_baseline"] = cpu_baseline(sd, torch.from_numpy(image_all[:4]), cfg)
+            res["cpu_baseline"] = cpu_baseline(sd, torch.from_numpy(image_all[:4]), cfg, args.config)
         print(json.dumps(res))
     if world > 1:
         dist.barrier()

@@ -235,7 +235,8 @@ int launch_attention_mfma(const float* qkv, float* out, int N, int T, int Ta, in
     // 8 waves (256 queries) per block for long sequences at head width 32: a key tile's staging (split to fp16 hi/lo, LDS writes) is
     // shared by twice as many queries — one item per thread instead of two
     // (T = 8192, N = 4, 4 heads: 570 -> 502 us = 29.0 -> 32.8 % of the fp16 matrix peak by instruction count; T = 2048: 90 -> 83 us)
-    static const int w8_min = getenv("CCDM_ATTN_W8_MIN") ? atoi(getenv("CCDM_ATTN_W8_MIN")) : 2048;      // A/B hook (0: never)
+    const int w8_env = exp_env("CCDM_ATTN_W8_MIN");      // A/B hook of CCDM_EXPERIMENTS builds (-1: never)
+    const int w8_min = w8_env ? w8_env : 2048;
     const int waves = (D == 32 && w8_min > 0 && T >= w8_min) ? 8 : (T >= 128 ? 4 : (T >= 64 ? 2 : 1));
     dim3 grid(cdiv(T, 32 * waves), heads, N);
     if (D == 64) {

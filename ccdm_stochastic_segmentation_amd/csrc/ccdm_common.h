@@ -31,6 +31,15 @@ int fail(const char* fmt, ...);
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Experiment switches (same-box A/B hooks of tools/): environment variables are read ONLY in a -DCCDM_EXPERIMENTS build
+// (CCDM_EXPERIMENTS=1 python -c "from ccdm_stochastic_segmentation_amd import hip; hip.build()"); the shipped library reads no
+// environment, allocates nothing and keeps no global state besides the thread-local error string.
+#ifdef CCDM_EXPERIMENTS
+static inline int exp_env(const char* name) { const char* v = getenv(name); return v ? atoi(v) : 0; }
+#else
+static inline constexpr int exp_env(const char*) { return 0; }
+#endif
+
 // ---- conv launch geometry (shared by the kernel dispatcher, the packer and ccdm_conv_slices) ----
 struct ConvGeo {
     int TH, TW, waves, MI;   // output tile, waves per block, 32-pixel sub-tiles per wave

@@ -39,10 +39,6 @@ namespace ccdm {
 // a branch around every store and every phase of the production kernel.
 //   1 no MFMA | 2 no commit | 4 no loads | 8 no stores | 16 phase timeline | 256 no barriers (wrong results)
 //   512 / 1024: pad the LDS request so that at most 2 / 1 blocks fit a CU (host side, always available)
-#ifndef CCDM_NT_STORES
-#define CCDM_NT_STORES 0
-#endif
-static constexpr bool NT_STORES = CCDM_NT_STORES != 0;     // experiment: outputs stored non-temporally
 #ifdef CCDM_ABLATION
 #define CCDM_DBG(bit) ((dbg & (bit)) != 0)
 #else
@@ -217,34 +213,13 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
     const int my_tiles = (ntile_sp - slice + k.slices - 1) / k.slices;
     const int n_iter = my_tiles * nchunk;
 
-    // Staging register sets.  DEPTH = 1: the halo of iteration i+1 is requested after the commit of iteration i and the
-    // weight fragments at the top of the iteration that consumes them (registers are the scarce resource of the wide-
-    // tile variants: 3 waves per SIMD).  DEPTH = 2 requests halo AND fragments of iteration i+2 as soon as iteration i has
-    // been committed (two iterations to land instead of one MFMA phase).  Built and parity-tested for the small-spatial
-    // CK = 32 variants, which have the registers for it — and measured neutral to slightly slower there (8x8 128->128:
-    // 15.1 -> 15.8 us; those kernels are bound by launch + prologue + epilogue, not by the round trip), so it is off.
-    //   Wide tiles, one n-tile (the 128x128 / 64x64 stages, HBM-bound): a second HALO set only (+4*NITEM registers, still
-    //   3 waves per SIMD); the fragments stay top-of-iteration.
-#ifndef CCDM_DEEP_PREFETCH
-#define CCDM_DEEP_PREFETCH 0
-#endif
-#ifndef CCDM_DEEP_HALO
-#define CCDM_DEEP_HALO 0      // same-box A/B: -1.5 % at 128x128, +4 % at 64x64 (L2 misses of the second half-lines vanish, 236 -> 174 MB fetched, time does not follow)
-#endif
-    constexpr bool DEEP_B = CCDM_DEEP_PREFETCH && PREC != CCDM_PREC_F32 && CKT == 32 && 8 * (NITEM + NITEM_B) <= 136;
-    constexpr bool DEEP_A = CCDM_DEEP_HALO && PREC != CCDM_PREC_F32 && STRIDE == 1 && TW == 32 && NI == 1 && !SKWT;
-    constexpr int DEPTH = (DEEP_A || DEEP_B) ? 2 : 1;
-    // EARLY_B (experiment, off): narrow-tile variants request the NEXT chunk's weight fragments together with the next halo, right
-    // after the commit has emptied the fragment registers, instead of at the top of the iteration that consumes them.  The timeline
-    // shows 1700 cycles of barrier wait for them in the second chunk of an 8x8 block, yet the whole LIDC step measured 0.5-1 % SLOWER
-    // with it (same box, 3.209 -> 3.233 ms): like the two-deep prefetch above, not a win.
-#ifndef CCDM_EARLY_B
-#define CCDM_EARLY_B 0
-#endif
-    constexpr bool EARLY_B = CCDM_EARLY_B && !DEEP_B && PREC != CCDM_PREC_F32 && TW < 32;
-    constexpr int DEPTH_B = DEEP_B ? 2 : 1;
+    // Staging register sets: ONE halo set and one fragment set.  The halo of iteration i+1 is requested right after the commit of
+    // iteration i; the weight fragments at the top of the iteration that consumes them (registers are the scarce resource of the
+    // wide-tile variants: 3 waves per SIMD).  Two-deep variants (a second halo set, fragments two iterations ahead, next-chunk fragments
+    // requested with the next halo) were built, parity-tested and measured neutral to slower in rounds 1-2; they are gone.
+    constexpr int DEPTH = 1;
     f32x4 reg[DEPTH][NITEM_R];
-    f32x4 regB[DEPTH_B][NITEM_B > 0 ? NITEM_B : 1];
+    f32x4 regB[1][NITEM_B > 0 ? NITEM_B : 1];
     unsigned valid[DEPTH];         // generic walk: bit i = item i lies inside the image
     unsigned rowmask[DEPTH];       // row-structured: bit i = core row of pass i inside the image (wave-uniform)
     unsigned evalid[DEPTH];        //                 bit j = edge item j inside the image
@@ -408,7 +383,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                 const unsigned rem = B_MULTI ? remb : remb + (unsigned)(NT * (i % DB) * 16);
                 ts = ts < nslab ? ts : 0u;
                 const unsigned slab = skwc ? ts * wks : (ts / KST) * wtap + (ts % KST) * wks;
-                regB[DEEP_B ? d : 0][i] = load16_uniform_base(wq + ((size_t)slab << 4), rem);
+                regB[0][i] = load16_uniform_base(wq + ((size_t)slab << 4), rem);
             }
         }
     };
@@ -514,7 +489,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
 #pragma unroll
             for (int i = 0; i < NITEM_B; ++i) {
                 const int j = (int)t_ + i * NT;
-                if ((i + 1) * NT <= NB4 || j < NB4) ldsB[j] = regB[DEEP_B ? d : 0][i];
+                if ((i + 1) * NT <= NB4 || j < NB4) ldsB[j] = regB[0][i];
             }
         }
     };
@@ -569,16 +544,10 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
     };
     int chunk = 0, cur_ty = slice / k.tiles_x, cur_tx = slice % k.tiles_x;
     int pf_ch = 0, pf_ty = cur_ty, pf_tx = cur_tx;
-    // prologue: fill every register set (sets beyond the last iteration request clamped addresses: harmless, branch-free)
+    // prologue: the first halo request
     // (a launch always has n_iter >= 1: slices <= tiles)
     issue(std::integral_constant<int, 0>{}, pf_ch, pf_ty, pf_tx);
-    if constexpr (DEEP_B || EARLY_B) issueB(std::integral_constant<int, 0>{}, pf_ch);
     advance(pf_ch, pf_ty, pf_tx);
-    if constexpr (DEPTH > 1) {
-        issue(std::integral_constant<int, 1>{}, pf_ch, pf_ty, pf_tx);
-        if constexpr (DEEP_B) issueB(std::integral_constant<int, 1>{}, pf_ch);
-        advance(pf_ch, pf_ty, pf_tx);
-    }
     __builtin_amdgcn_sched_barrier(0);
     CCDM_STAMP(13);
     // the small loads issued at the top are consumed here, behind the first halo request
@@ -605,7 +574,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                     for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
         }
         CCDM_STAMP(2);
-        if constexpr (!DEEP_B && !EARLY_B) { if (!CCDM_DBG(4)) issueB(D_, chunk); }
+        if (!CCDM_DBG(4)) issueB(D_, chunk);
         if (!CCDM_DBG(256)) __syncthreads();          // previous MFMA phase has finished reading LDS (and ab[] is visible)
         CCDM_STAMP(3);
         if (!CCDM_DBG(2)) commit(D_, chunk);
@@ -616,7 +585,6 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
         // slice's last one: addresses are clamped into the tensor, the data is never committed — harmless, branch-free)
         if (!CCDM_DBG(4)) {       // refill the set just committed: iteration it + DEPTH
             issue(D_, pf_ch, pf_ty, pf_tx);
-            if constexpr (DEEP_B || EARLY_B) issueB(D_, pf_ch);
             advance(pf_ch, pf_ty, pf_tx);
         }
 
@@ -848,7 +816,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                                 v += *reinterpret_cast<const f32x4*>(epi0 + g * (WAVES * MI * 32 * EPS) + pl * EPS + 4 * cq);
                             if (RESID) v += rs[j];
                             if (FULL) {
-                                if (!CCDM_DBG(8)) store16_uniform_base<NT_STORES>(reinterpret_cast<char*>(outn) + row_base(j), lane_off, v);
+                                if (!CCDM_DBG(8)) store16_uniform_base(reinterpret_cast<char*>(outn) + row_base(j), lane_off, v);
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) { t1[e] += v[e]; t2[e] = fmaf(v[e], v[e], t2[e]); }
                             } else {
@@ -904,10 +872,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
         }
         advance(chunk, cur_ty, cur_tx);
     };
-    for (int it = 0; it < n_iter; it += DEPTH) {
-        iterate(std::integral_constant<int, 0>{});
-        if constexpr (DEPTH > 1) { if (it + 1 < n_iter) iterate(std::integral_constant<int, 1>{}); }
-    }
+    for (int it = 0; it < n_iter; ++it) iterate(std::integral_constant<int, 0>{});
 
     CCDM_STAMP(8);
     if (CCDM_DBG(16) && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && tid == 0) g_timeline[1023] = tl;
@@ -975,8 +940,7 @@ static int chunk_ck(const ccdm_conv_args& a, const ConvGeo& g) {
     const bool ok64 = ok32 && g.TW == 8 && C % 64 == 0 && (a.C1 == 0 || a.C0 % 64 == 0) &&
                       (!a.skip0 || (SC % 64 == 0 && (a.SC1 == 0 || a.SC0 % 64 == 0))) &&
                       (a.ksize == 1 || tap_split(a, g));
-    static const int no64 = getenv("CCDM_NO_CK64") ? atoi(getenv("CCDM_NO_CK64")) : 0;     // A/B hook
-    return ok64 && !no64 ? 64 : (ok32 ? 32 : 16);
+    return ok64 && !exp_env("CCDM_NO_CK64") ? 64 : (ok32 ? 32 : 16);
 }
 
 static bool tap_split(const ccdm_conv_args& a, const ConvGeo& g) {
@@ -1073,7 +1037,7 @@ static int conv_slices_default(int tiles, bool up2) {
     // 48 blocks on 256 CUs).  More than CCDM_STATS_MAX_SLICES partials are folded to 16 by ccdm_stats_fold before a GroupNorm
     // reads them.  A function of the spatial size only (never of N): sharding the batch must not change the order in which
     // statistics partials are added.
-    static const int ovr = getenv("CCDM_SLICES") ? atoi(getenv("CCDM_SLICES")) : 0;     // experiment hook
+    const int ovr = exp_env("CCDM_SLICES");
     if (ovr > 0 && ovr <= CCDM_STATS_MAX_SLICES && tiles >= ovr) return ovr;
     // Tile counts that only Cityscapes-sized images produce (64x128 and 32x64 with 8x16 tiles: 32 tiles; 128x256: 128 tiles) come with
     // batches of 4-16 samples: one slice per tile / per four tiles there (C5 shard 14.26 -> 13.24 ms, C4 7.13 -> 6.84 ms per step)
@@ -1172,8 +1136,7 @@ int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
     const int HP = ((g.TH - 1) * a.stride + a.ksize) * ((g.TW - 1) * a.stride + a.ksize);
     const int ck = chunk_ck(a, g);
     {   // wide skip chunks (k_conv, SKW): the wide-tile F16X3 one-n-tile variant, skip sources in multiples of 32 channels
-        static const int no_skw = getenv("CCDM_NO_SKIP_WIDE") ? atoi(getenv("CCDM_NO_SKIP_WIDE")) : 0;      // same-box A/B hook
-        k.skip_wide = (!no_skw && a.skip0 && prec == CCDM_PREC_F16X3 && a.ksize == 3 && a.stride == 1 && !a.up && g.TW == 32 && NI == 1 && ck == 16 &&
+        k.skip_wide = (!exp_env("CCDM_NO_SKIP_WIDE") && a.skip0 && prec == CCDM_PREC_F16X3 && a.ksize == 3 && a.stride == 1 && !a.up && g.TW == 32 && NI == 1 && ck == 16 &&
                        a.SC0 % 32 == 0 && a.SC1 % 32 == 0 && !(a.prec >> 8)) ? 1 : 0;
     }
     {   // core halo items need no per-lane padding mask when every tile column and every channel quad exists (see ConvK)
@@ -1202,12 +1165,14 @@ int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
     if ((a.prec >> 8) & 512) lds = 60 * 1024;      // diagnostics (tools/bench_conv.py): at most 2 blocks per CU
     if ((a.prec >> 8) & 1024) lds = 100 * 1024;    //                                   1 block per CU
     CCDM_REQUIRE(lds <= 160 * 1024, "conv: LDS %zu too large", lds);
-    if (conv_pc_eligible(k, g, NI)) {          // full-width 3x3 stages: producer/consumer form (ccdm_conv_pc.hip)
+#ifdef CCDM_EXPERIMENTS
+    if (conv_pc_eligible(k, g, NI)) {          // full-width 3x3 stages: producer/consumer form (tools/experiments/ccdm_conv_pc.hip, CCDM_PC=1)
         const int rc_pc = launch_conv_pc(k, s);
         if (rc_pc) return rc_pc;
         CCDM_CHECK_LAUNCH("conv(pc)");
         return 0;
     }
+#endif
     dim3 grid(a.N * k.slices, k.ntiles / NI);
     const int rc = prec == CCDM_PREC_F32 ? launch_prec<CCDM_PREC_F32>(k, g, NI, ck, grid, lds, s)
                                            : launch_prec<CCDM_PREC_F16X3>(k, g, NI, ck, grid, lds, s);
@@ -1239,7 +1204,9 @@ extern "C" int ccdm_conv_slices_ex(int Hin, int Win, int ksize, int stride, int 
 
 extern "C" int ccdm_debug_read_timeline(unsigned long long* host, int n) {
     if (!host || n <= 0 || n > 1024) return ccdm::fail("debug_read_timeline: bad args");
+#ifdef CCDM_EXPERIMENTS
     if (ccdm::conv_pc_timeline_read(host, n)) return 0;
+#endif
     if (hipMemcpyFromSymbol(host, HIP_SYMBOL(ccdm::g_timeline), (size_t)n * 8, 0, hipMemcpyDeviceToHost) != hipSuccess)
         return ccdm::fail("debug_read_timeline: copy failed");
     return 0;

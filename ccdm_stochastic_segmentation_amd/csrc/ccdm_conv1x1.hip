@@ -263,14 +263,15 @@ static int conv1x1_px_per_block(const ccdm_conv_args& a, int slices) {
 
 // 1x1 conv of a low-resolution tensor: the whole geometry must tile exactly (no masks in the kernel)
 bool conv1x1_eligible(const ccdm_conv_args& a, int slices) {
-    const int off = getenv("CCDM_NO_CONV1X1") ? atoi(getenv("CCDM_NO_CONV1X1")) : 0;      // A/B and test hook (read per call)
-    if (off || a.prec != CCDM_PREC_F16X3) return false;                        // (ablation bits in prec: general kernel)
+    if (a.prec != CCDM_PREC_F16X3) return false;                               // (any diagnostic bit in prec >> 8, e.g. CCDM_DIAG_GENERAL_KERNEL: general kernel)
     if (a.ksize != 1 || a.stride != 1 || a.up || a.act != CCDM_ACT_NONE || a.film || a.skip0 || a.emb_off >= 0 || a.in1) return false;
     const int HW = a.Hout * a.Wout;
     if (a.C0 % 16 || a.Cout % 32 || a.C0 > CCDM_MAX_CHANNELS) return false;
     const int ppb = conv1x1_px_per_block(a, slices);
     if (a.stats0 && ppb > 128) return false;                                   // the GroupNorm variant is planned for 4-wave blocks (registers)
-    return ppb > 0 && (long long)a.N * (HW / ppb) * (a.Cout / 32) <= 8192;      // low-resolution stages only
+    // low-resolution stages only — a rule of the geometry alone, never of the batch size: this kernel and the general one partition the
+    // output statistics differently, so the choice must not change when a batch is sharded over ranks or sub-batches
+    return ppb > 0 && HW <= 16384;
 }
 
 int launch_conv1x1(const ccdm_conv_args& a, int slices, int ntiles, const float* wscale, hipStream_t s) {

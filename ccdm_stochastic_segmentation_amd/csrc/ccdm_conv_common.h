@@ -53,17 +53,19 @@ struct ConvK {   // kernel-side copy of ccdm_conv_args (+ derived)
     const float* wscale;     // F16X3: [ntiles*32] powers of two undoing the per-output-channel weight pre-scale
     int core_unmasked;       // every core column of every tile lies inside the image and every channel quad exists (W % TW == 0, C % CK == 0):
                              // core halo items need no per-lane padding mask, only the wave-uniform row test
-    unsigned long long* timeline;   // diagnostics (CCDM_PC_TIMELINE=1): s_memtime stamps of one mid-grid block, else NULL
+    unsigned long long* timeline;   // diagnostics of the producer/consumer experiment (CCDM_EXPERIMENTS builds), else NULL
 };
 
 // plain 1x1 conv (+bias +residual +statistics) of a low-resolution tensor without LDS staging (ccdm_conv1x1.hip)
 bool conv1x1_eligible(const ccdm_conv_args& a, int slices);
 int launch_conv1x1(const ccdm_conv_args& a, int slices, int ntiles, const float* wscale, hipStream_t s);
 
-// producer/consumer form of the full-width 3x3 stages (ccdm_conv_pc.hip)
+#ifdef CCDM_EXPERIMENTS
+// producer/consumer form of the full-width 3x3 stages (tools/experiments/ccdm_conv_pc.hip: measured slower, never in the shipped library)
 bool conv_pc_eligible(const ConvK& k, const ConvGeo& g, int NI);
 int launch_conv_pc(const ConvK& k, hipStream_t s);
 bool conv_pc_timeline_read(unsigned long long* host, int n);
+#endif
 
 // ---------------------------------------------------------------------------------------------------
 // GroupNorm affine for sample n:  ab[c] = (scale, shift) such that  y = scale*x + shift

@@ -58,9 +58,9 @@ def sample_sharded(model, x: torch.Tensor, condition: torch.Tensor, feature_cond
                    t: Optional[torch.Tensor] = None, gather=True) -> torch.Tensor:
     """Run `model` (a DenoisingModel-like callable) on this rank's shard of the global batch and return the
     full [N,K,H,W] prediction on every rank, or only the local shard (gather=False).
-    gather=True: the predictions travel as they are (fp32 probabilities / int64 one-hot);
-    gather="index": only the uint8 argmax map travels (K*8 x fewer bytes for one-hot "majority" outputs: 16 MB instead of
-    1.3 GB at BASELINE config C5) and the one-hot is rebuilt on arrival in the model's output dtype."""
+    gather=True: fp32 probabilities travel as they are; int64 one-hot ("majority") predictions travel as their uint8 argmax map
+    (K*8 x fewer bytes: 16 MB instead of 1.3 GB at BASELINE config C5) and are rebuilt on arrival;
+    gather="index": force the index form for any output (fp32 one-hot of a shortened walk)."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     n = x.shape[0]
@@ -78,24 +78,39 @@ def sample_sharded(model, x: torch.Tensor, condition: torch.Tensor, feature_cond
         model.noise_slice = None
     if world == 1 or not gather:
         return out
-    if gather == "index":
+    # one-hot ("majority") predictions are int64 in the reference's contract: only their uint8 argmax map needs to travel
+    # (K * 8 x fewer bytes: 16 MB instead of 1.3 GB at BASELINE config C5), the one-hot is rebuilt on arrival
+    if gather == "index" or out.dtype == torch.int64:
         K = out.shape[1]
         idx = all_gather_ragged(out.argmax(dim=1).to(torch.uint8).contiguous(), n, world)
         return torch.nn.functional.one_hot(idx.long(), K).permute(0, 3, 1, 2).to(out.dtype)
     return all_gather_ragged(out, n, world)
 
 
-def all_gather_ragged(local: torch.Tensor, n: int, world: int) -> torch.Tensor:
-    """all_gather of per-rank shards whose first dims follow shard_range (pads to the largest shard).  RCCL moves device
-    tensors directly; under the gloo backend (CPU tests, or several ranks sharing one GPU) the shards travel through the host."""
+def all_gather_shards(local: torch.Tensor, n: int, world: int, buf: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """ONE all_gather_into_tensor of per-rank shards whose first dims follow shard_range, into a preallocated buffer (pass the returned
+    `buf` back in on the next call: no per-call allocation, one collective whatever the rank count).  Ragged shards are padded to the
+    largest.  RCCL moves device tensors directly; under the gloo backend (CPU tests, or several ranks sharing one GPU) the shards
+    travel through the host.  Returns (full [n, ...] tensor on local's device, buf)."""
     sizes = [shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world)]
     m = max(sizes)
     dev = local.device
-    pad = local
+    pad = local.contiguous()
     if dist.get_backend() == "gloo" and local.is_cuda:
         pad = pad.cpu()
     if pad.shape[0] < m:
         pad = torch.cat([pad, pad.new_zeros((m - pad.shape[0],) + tuple(pad.shape[1:]))], 0)
-    bufs = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(bufs, pad.contiguous())
-    return torch.cat([b[:s] for b, s in zip(bufs, sizes)], 0).to(dev)
+    shape = (world * m,) + tuple(pad.shape[1:])
+    if buf is None or tuple(buf.shape) != shape or buf.dtype != pad.dtype or buf.device != pad.device:
+        buf = torch.empty(shape, dtype=pad.dtype, device=pad.device)
+    dist.all_gather_into_tensor(buf, pad)
+    if all(sz == m for sz in sizes):
+        full = buf
+    else:
+        full = torch.cat([buf[r * m:r * m + sz] for r, sz in enumerate(sizes)], 0)
+    return full.to(dev), buf
+
+
+def all_gather_ragged(local: torch.Tensor, n: int, world: int) -> torch.Tensor:
+    """all_gather_shards without buffer reuse (one-off calls)."""
+    return all_gather_shards(local, n, world)[0]

@@ -459,14 +459,24 @@ class SamplerEngine:
             return None
         return self.head_ce.buf[..., : self.K - 1].clone().permute(0, 3, 1, 2)
 
+    def check_and_clear_flag(self) -> bool:
+        """Synchronises with the engine's stream; True (and the flag cleared) if any head output of the runs since the last check was
+        not finite."""
+        if int(self.flag.item()) != 0:
+            self.flag.zero_()
+            return True
+        return False
+
+    def raise_range_error(self) -> None:
+        raise hip.CcdmRangeError(
+            "the network output is not finite" + (": a staged activation left the range of the fp16 split (|a| >= 4094, "
+            "include/ccdm_hip.h); re-run with prec=PREC_F32" if self.prec == hip.PREC_F16X3 else " (exact-fp32 kernels: check the weights and inputs)"))
+
     def raise_if_flagged(self) -> None:
         """Synchronises with the engine's stream.  Raises CcdmRangeError (and clears the flag) if any head output of the runs
         since the last check was not finite."""
-        if int(self.flag.item()) != 0:
-            self.flag.zero_()
-            raise hip.CcdmRangeError(
-                "the network output is not finite" + (": a staged activation left the range of the fp16 split (|a| >= 4094, "
-                "include/ccdm_hip.h); re-run with prec=PREC_F32" if self.prec == hip.PREC_F16X3 else " (exact-fp32 kernels: check the weights and inputs)"))
+        if self.check_and_clear_flag():
+            self.raise_range_error()
 
     # timing taps for bench.py: HIP events on the engine's stream around every launch of the tapped ops
     def profile_op(self, op_index: int, capacity: int = 4096) -> None:

@@ -140,8 +140,8 @@ def apply_sampler_options(model, params: dict) -> None:
         raise ValueError(f"prec: {prec!r} (expected 'f16x3' or 'f32')")
     model.prec = hip.PREC_F32 if prec == "f32" else hip.PREC_F16X3
     model.philox_seed = int(params.get("philox_seed", 0))
-    model.use_graph = bool(params.get("use_graph", False))
-    model.substreams = int(params.get("substreams", 1))          # 0 = automatic (DenoisingModel)
+    model.use_graph = bool(params.get("use_graph", True))
+    model.substreams = int(params.get("substreams", 0))          # 0 = automatic (DenoisingModel)
     model.on_range_error = str(params.get("on_range_error", "f32"))
     model.slicing = str(params.get("slicing", "throughput"))
     model._fine_slices(1)                                         # validates the value

@@ -15,13 +15,17 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("CCDM_LIB") or os.path.join(_HERE, "libccdm_hip.so")      # CCDM_LIB: A/B two builds on one GPU box
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["ccdm_conv.hip", "ccdm_conv_pc.hip", "ccdm_conv1x1.hip", "ccdm_misc.hip", "ccdm_attention.hip", "ccdm_attn_block.hip", "ccdm_sampler.hip", "ccdm_metrics.hip", "ccdm_engine.hip"]
+SOURCES = ["ccdm_conv.hip", "ccdm_conv1x1.hip", "ccdm_misc.hip", "ccdm_attention.hip", "ccdm_attn_block.hip", "ccdm_sampler.hip", "ccdm_metrics.hip", "ccdm_engine.hip"]
+# CCDM_EXPERIMENTS=1 builds add the measured-and-rejected kernels of tools/experiments/ and the environment switches the A/B tools use
+# (exp_env in ccdm_common.h); the shipped library contains neither
+EXPERIMENT_SOURCES = [os.path.join(ROOT, "tools", "experiments", "ccdm_conv_pc.hip")]
 # -amdgpu-mfma-vgpr-form: MFMA accumulators stay in the (unified) VGPR file.  The default heuristic parks them in AccVGPRs and pays a
 # v_accvgpr_read/_write for every vector op that touches a score or an output accumulator: 240 extra instructions per key tile in
 # the attention kernels (2066 in ccdm_attention.hip, 576 in ccdm_attn_block.hip; the conv kernels have none either way).
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fPIC", "-shared"]
 
 ACT_NONE, ACT_SILU = 0, 1
+DIAG_GENERAL_KERNEL = 2048 << 8     # CCDM_DIAG_GENERAL_KERNEL: OR into ConvArgs.prec to bypass the specialised conv kernels (parity tests)
 PREC_F32, PREC_F16X3 = 0, 1
 STEP_SAMPLE, STEP_LAST_CONFIDENCE, STEP_LAST_MAJORITY, STEP_LAST_KEEP, STEP_SOFTMAX_ONLY = 0, 1, 2, 3, 4
 STATS_MAX_SLICES = 64       # CCDM_STATS_MAX_SLICES: what a GroupNorm consumer reads
@@ -141,12 +145,24 @@ def build(force: bool = False, verbose: bool = False) -> str:
     """Compile libccdm_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).  One object per source,
     compiled in parallel into <package>/build/ (only the sources that changed), then linked."""
     from concurrent.futures import ThreadPoolExecutor
+    import hashlib
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     hdrs = [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".h")] + [os.path.join(ROOT, "include", "ccdm_hip.h")]
     extra = ["-DCCDM_ABLATION"] if os.environ.get("CCDM_ABLATION") else []      # tools/bench_conv.py ABLATE / TIMELINE modes
-    extra += os.environ.get("CCDM_HIPCC_EXTRA", "").split()                     # experiments, e.g. -DCCDM_NT_STORES=1
-    objdir = os.path.join(_HERE, "build", "obj" + ("_" + str(abs(hash(tuple(extra))) % 10 ** 8) if extra else ""))
+    if os.environ.get("CCDM_EXPERIMENTS"):
+        extra += ["-DCCDM_EXPERIMENTS", "-I" + CSRC]
+        srcs += EXPERIMENT_SOURCES
+    extra += os.environ.get("CCDM_HIPCC_EXTRA", "").split()                     # one-off experiments
+    # one object directory per build flavour (stable name), and a stamp next to the library saying which flavour it was linked from:
+    # a plain build after an ablation / experiments build must relink, not return the other flavour's library
+    flavour = hashlib.sha1(" ".join(extra).encode()).hexdigest()[:10] if extra else "default"
+    objdir = os.path.join(_HERE, "build", "obj" + ("" if flavour == "default" else "_" + flavour))
     os.makedirs(objdir, exist_ok=True)
+    stamp = LIB_PATH + ".flavour"
+    try:
+        linked_flavour = open(stamp).read().strip()
+    except OSError:
+        linked_flavour = None
     newest_hdr = max(os.path.getmtime(h) for h in hdrs)
     flags = [f for f in HIPCC_FLAGS if f != "-shared"]
 
@@ -165,7 +181,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 1)) as ex:
         res = list(ex.map(compile_one, srcs))
     objs = [o for o, _ in res]
-    if not force and not any(c for _, c in res) and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(o) for o in objs):
+    if not force and not any(c for _, c in res) and os.path.exists(LIB_PATH) and linked_flavour == flavour and \
+            all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(o) for o in objs):
         return LIB_PATH
     cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH]
     if verbose:
@@ -173,6 +190,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise CcdmHipError("hipcc link failed:\n" + r.stdout + r.stderr)
+    with open(stamp, "w") as fh:
+        fh.write(flavour + "\n")
     return LIB_PATH
 
 

@@ -258,8 +258,14 @@ HOST_NOISE_BLOCK_BYTES = 256 << 20
 
 class DenoisingModel(nn.Module):
     """The sampler.  `rng` selects where the Exp(1) noise of the categorical draws comes from:
-    "philox" (default) — Philox4x32-10 inside the epilogue kernel, keyed by (pixel, global sample index, step): the
-      throughput mode, statistically identical to the reference's draws;
+    "philox" (default) — Philox4x32-10 inside the epilogue kernel, keyed by (pixel, global sample index, step) under a 64-bit key
+      derived from (`philox_seed`, `philox_call`): the throughput mode, statistically identical to the reference's draws.
+      `philox_call` counts the sampling calls made on this model and advances by one after every `forward_denoising`, so successive
+      calls — the batches of an evaluation loop, S calls at batch 1 to draw S samples of one image — see independent noise, like
+      successive draws from the reference's generator do.  The key does not depend on how the batch is split over ranks or
+      sub-batches (every rank makes the same sequence of calls), so sharding stays invariant; set `philox_call` back (or
+      `philox_advance = False`) to replay a call bit for bit.  torch.manual_seed does not reach this stream: seed it with
+      `philox_seed` (params file key of the same name);
     "torch_cpu" — drawn on the host from torch's global CPU generator in exactly the order the reference's CPU path
       consumes it (parity mode: seeded runs reproduce the reference's class indices; the host RNG is the bottleneck).
     `prec` selects the conv arithmetic: hip.PREC_F16X3 (default; fp16 hi/lo split x3 on the matrix cores, ~2^-22 per
@@ -274,14 +280,17 @@ class DenoisingModel(nn.Module):
         self.step_T_sample = step_T_sample
         self.rng = "philox"
         self.philox_seed = 0
+        self.philox_call = 0            # index of the next sampling call's noise stream (see the class docstring)
+        self.philox_advance = True
         self.sample_offset = 0          # global index of sample 0 when the batch is sharded over ranks
         self.noise_slice: Optional[Tuple[int, int]] = None   # (global_batch, first_sample) for torch_cpu sharding
-        self.use_graph = False
-        # the batch is sampled as this many contiguous sub-batches on concurrent HIP streams (bit-identical samples).  2 is worth
-        # +5 % at N = 64 (the low-resolution kernels of one half run beside the full-width kernels of the other; bench.py reports it
-        # as `substreams2`); the default stays 1 so that a kernel's measured duration describes that kernel.  0 = automatic: two
-        # from 32 samples up, one below.
-        self.substreams = 1
+        # each denoise step is replayed as one captured HIP graph (identical results to eager launches, tested)
+        self.use_graph = True
+        # the batch is sampled as this many contiguous sub-batches on concurrent HIP streams (bit-identical samples).  0 (default) =
+        # automatic: two from 32 samples up (+7-10 % at N = 64: the low-resolution kernels of one half run beside the full-width
+        # kernels of the other), one below.  bench.py times this default and collects its per-kernel taps in a separate
+        # single-stream pass (under concurrency a launch's duration no longer describes the kernel).
+        self.substreams = 0
         self.prec = hip.PREC_F16X3
         # what to do when a PREC_F16X3 run reports a range overflow (hip.CcdmRangeError): "f32" = repeat the call with the
         # exact-fp32 kernels (same seeds, so the samples are the ones an all-fp32 run would have drawn) and log a warning;
@@ -350,6 +359,15 @@ class DenoisingModel(nn.Module):
         self._engines[key] = (wkey, eng)
         return eng
 
+    def _philox_key(self) -> int:
+        """64-bit Philox key of the current sampling call: splitmix64 of (philox_seed, philox_call)."""
+        if int(self.philox_call) == 0:
+            return int(self.philox_seed) & 0xFFFFFFFFFFFFFFFF        # call 0 uses the seed itself (the key the kernel tests pin)
+        z = (int(self.philox_seed) + 0x9E3779B97F4A7C15 * int(self.philox_call)) & 0xFFFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        return z ^ (z >> 31)
+
     @staticmethod
     def _to_index(x: Tensor, device) -> Tensor:
         return x.argmax(dim=1).to(device=device, dtype=torch.uint8).contiguous()
@@ -375,7 +393,10 @@ class DenoisingModel(nn.Module):
 
     def forward_denoising(self, x: Optional[Tensor], condition: Tensor, feature_condition: Tensor,
                           init_t: Optional[int] = None, label_ref_logits: Optional[Tensor] = None) -> dict:
-        return self._with_range_fallback(lambda: self._forward_denoising(x, condition, feature_condition, init_t, label_ref_logits))
+        out = self._with_range_fallback(lambda: self._forward_denoising(x, condition, feature_condition, init_t, label_ref_logits))
+        if self.philox_advance:
+            self.philox_call += 1           # the next call draws from a fresh stream (a range-error re-run above replayed this one)
+        return out
 
     def _forward_step(self, x: Tensor, condition: Tensor, feature_condition: Tensor, t: Tensor) -> dict:
         """One U-Net evaluation at per-sample timesteps `t` (diffusion_denoising.py:161-162 -> unet.py:744-808): the
@@ -416,6 +437,7 @@ class DenoisingModel(nn.Module):
         if self.rng not in ("philox", "torch_cpu"):
             raise ValueError(f"unknown rng mode {self.rng!r}")
         host_rng = self.rng == "torch_cpu"
+        key = self._philox_key()
         gN, first = self.noise_slice if (host_rng and self.noise_slice is not None) else (N, 0)
         # Samples are independent through all T steps: the batch may be walked as several contiguous
         # sub-batches, each with its own step executor on its own HIP stream.  The kernels of the low-resolution stages
@@ -454,12 +476,12 @@ class DenoisingModel(nn.Module):
                     with torch.cuda.stream(eng.stream):
                         noises[j] = host[:, first + lo:first + hi].contiguous().to(eng.device)
             if nsub == 1:
-                parts[0][0].run(s1 - s0, first_row=s0, noise=noises[0], noise_row0=s0, philox_seed=self.philox_seed,
+                parts[0][0].run(s1 - s0, first_row=s0, noise=noises[0], noise_row0=s0, philox_seed=key,
                                 sample_offset=self.sample_offset, use_graph=self.use_graph)
             else:
                 for s in range(s0, s1):              # one step of every sub-batch in turn: the streams advance side by side
                     for j, (eng, lo, hi) in enumerate(parts):
-                        eng.run(1, first_row=s, noise=noises[j], noise_row0=s0, philox_seed=self.philox_seed,
+                        eng.run(1, first_row=s, noise=noises[j], noise_row0=s0, philox_seed=key,
                                 sample_offset=self.sample_offset + lo, use_graph=self.use_graph)
         outs = []
         for eng, lo, hi in parts:
@@ -473,8 +495,11 @@ class DenoisingModel(nn.Module):
                     out = eng.out_onehot.clone().permute(0, 3, 1, 2)
             eng.leave()
             outs.append(out)
-        for eng, lo, hi in parts:
-            eng.raise_if_flagged()
+        # read AND clear the sticky range flag of every sub-batch engine before raising: a flag left set on a cached engine would
+        # fail the next, unrelated call on it
+        flagged = [eng.check_and_clear_flag() for eng, lo, hi in parts]
+        if any(flagged):
+            parts[0][0].raise_range_error()
         out = outs[0] if nsub == 1 else torch.cat(outs, 0)
         if out.device != x.device:
             out = out.to(x.device)

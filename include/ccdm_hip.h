@@ -55,6 +55,10 @@ enum { CCDM_PREC_F32 = 0,      /* v_mfma_f32_32x32x2_f32: exact fp32 products an
  * clipped number; the step epilogue (ccdm_post_args.range_flag) turns that into a sticky device flag the host checks.
  * Below |a| ~ 2e-3 the split keeps an ABSOLUTE error <= 2^-29 (fp16 subnormal spacing after the 2^4 pre-scale). */
 
+/* Diagnostic bit of ccdm_conv_args.prec (bits 8 and up are diagnostics; the arithmetic is prec & 255): run the general staging kernel
+ * even where a specialised one applies (the LDS-free 1x1 kernel).  The parity tests use it to require identical bits from both. */
+#define CCDM_DIAG_GENERAL_KERNEL (2048 << 8)
+
 typedef struct ccdm_conv_args {
     /* input: virtual channel concat [in0 | in1] (in1 may be NULL); both [N,Hin,Win,C*] */
     const float* in0; const float* in1; int32_t C0; int32_t C1;

@@ -30,7 +30,7 @@ def gn_stats(x_nhwc: torch.Tensor, slices: int = 1) -> torch.Tensor:
 
 
 def conv2d(srcs, weight, bias, ksize, *, stats=None, gamma=None, beta=None, act=hip.ACT_NONE, stride=1, up=False,
-           emb=None, emb_rows=None, film=None, resid=None, want_stats=True, prec=hip.PREC_F32, skip=None, bench=None, fine=False):
+           emb=None, emb_rows=None, film=None, resid=None, want_stats=True, prec=hip.PREC_F32, skip=None, bench=None, fine=False, diag=0):
     """srcs: list of 1-2 NHWC cuda tensors; weight OIHW numpy/torch cpu; stats: list of stats tensors or None.
     emb: [rows, E] cpu tensor added per output channel (row per sample via emb_rows) ; film: (table cpu [rows, 2C]).
     Returns (out NHWC cuda, out_stats or None)."""
@@ -71,7 +71,7 @@ def conv2d(srcs, weight, bias, ksize, *, stats=None, gamma=None, beta=None, act=
     args.eps, args.act = 1e-5, act
     args.N, args.Hin, args.Win, args.Hout, args.Wout = N, Hin, Win, Hout, Wout
     args.ksize, args.stride, args.up, args.fine_slices = ksize, stride, int(up), int(fine)      # fine: False / True (level 1) / 2
-    args.w, args.bias, args.Cout, args.prec = wdev.data_ptr(), bdev.data_ptr(), cout, prec
+    args.w, args.bias, args.Cout, args.prec = wdev.data_ptr(), bdev.data_ptr(), cout, prec | int(diag)      # diag: hip.DIAG_* bits
     args.emb_off = -1
     table = emb if emb is not None else film
     if table is not None:

@@ -201,7 +201,7 @@ def test_conv_latency_slicing(U, c0, cout, H, W, k, stride, up):
 
 @pytest.mark.parametrize("cin,cout,H,W,resid", [(128, 128, 8, 8, 1), (96, 96, 16, 16, 1), (256, 128, 8, 8, 0), (64, 160, 16, 8, 1), (32, 32, 8, 8, 1),
                                                  (256, 256, 16, 32, 1), (128, 128, 32, 64, 1)])
-def test_plain_1x1_conv_kernel(U, cin, cout, H, W, resid, monkeypatch):
+def test_plain_1x1_conv_kernel(U, cin, cout, H, W, resid):
     """AttentionBlock.proj_out + residual (unet.py:300,311) on the LDS-free 1x1 kernel (ccdm_conv1x1.hip): against the fp64 operator,
     bit-identical to the general conv kernel's 1x1 path (same products, same order), statistics = those of what was stored."""
     rng = np.random.default_rng(cin + cout + H)
@@ -212,11 +212,8 @@ def test_plain_1x1_conv_kernel(U, cin, cout, H, W, resid, monkeypatch):
     res = rnd(rng, N, cout, H, W) if resid else None
     ref = F.conv2d(x.double(), w.double(), b.double()) + (res.double() if resid else 0)
     xs, rs_ = U.nhwc(x), (U.nhwc(res) if resid else None)
-    monkeypatch.delenv("CCDM_NO_CONV1X1", raising=False)
     out, ost = U.conv2d([xs], w.numpy(), b.numpy(), 1, resid=rs_, prec=hip.PREC_F16X3)
-    monkeypatch.setenv("CCDM_NO_CONV1X1", "1")
-    gen, gst = U.conv2d([xs], w.numpy(), b.numpy(), 1, resid=rs_, prec=hip.PREC_F16X3)
-    monkeypatch.delenv("CCDM_NO_CONV1X1")
+    gen, gst = U.conv2d([xs], w.numpy(), b.numpy(), 1, resid=rs_, prec=hip.PREC_F16X3, diag=hip.DIAG_GENERAL_KERNEL)
     got = U.bchw(out)
     np.testing.assert_allclose(got.numpy(), ref.float().numpy(), rtol=0, atol=2e-5)
     assert torch.equal(out, gen)
@@ -228,7 +225,7 @@ def test_plain_1x1_conv_kernel(U, cin, cout, H, W, resid, monkeypatch):
 
 
 @pytest.mark.parametrize("cin,cout,H,W", [(128, 384, 32, 64), (256, 768, 16, 32), (96, 288, 16, 16), (128, 384, 64, 128)])
-def test_norm_qkv_1x1_conv_kernel(U, cin, cout, H, W, monkeypatch):
+def test_norm_qkv_1x1_conv_kernel(U, cin, cout, H, W):
     """AttentionBlock.norm + qkv (unet.py:291-299,306) where the fused attention kernel does not apply: GroupNorm on load in the
     LDS-free 1x1 kernel — against the fp64 operator and bit-identical to the general conv kernel."""
     rng = np.random.default_rng(cin + H)
@@ -240,11 +237,9 @@ def test_norm_qkv_1x1_conv_kernel(U, cin, cout, H, W, monkeypatch):
     ref = F.conv2d(F.group_norm(x.double(), 32, g.double(), be.double(), 1e-5), w.double(), b.double())
     xs = U.nhwc(x)
     st = U.gn_stats(xs, 4)
-    monkeypatch.delenv("CCDM_NO_CONV1X1", raising=False)
     out, _ = U.conv2d([xs], w.numpy(), b.numpy(), 1, stats=[st], gamma=g.numpy(), beta=be.numpy(), prec=hip.PREC_F16X3, want_stats=False)
-    monkeypatch.setenv("CCDM_NO_CONV1X1", "1")
-    gen, _ = U.conv2d([xs], w.numpy(), b.numpy(), 1, stats=[st], gamma=g.numpy(), beta=be.numpy(), prec=hip.PREC_F16X3, want_stats=False)
-    monkeypatch.delenv("CCDM_NO_CONV1X1")
+    gen, _ = U.conv2d([xs], w.numpy(), b.numpy(), 1, stats=[st], gamma=g.numpy(), beta=be.numpy(), prec=hip.PREC_F16X3, want_stats=False,
+                      diag=hip.DIAG_GENERAL_KERNEL)
     np.testing.assert_allclose(U.bchw(out).numpy(), ref.float().numpy(), rtol=0, atol=3e-5)
     assert torch.equal(out, gen)
 
@@ -587,6 +582,7 @@ def test_full_size_properties_c2(U, lidc_model):
     image = torch.from_numpy(rng.uniform(-1, 1, (N, 1, 128, 128)).astype(np.float32)).to(U.DEV)
     x = O.one_hot_bchw(torch.from_numpy(rng.integers(0, 2, (N, 128, 128))), 2).to(U.DEV)
     model.rng, model.philox_seed, model.step_T_sample = "philox", 99, "confidence"
+    model.philox_advance = False      # this test replays the same noise stream call after call
     outs = []
     for graph in (False, False, True):
         model.use_graph = graph
@@ -711,6 +707,7 @@ def test_c4_shaped_step_vs_oracle(U, parity_log):
     assert err < 1e-4
     # two strided sampling steps run end to end with the device RNG and stay normalised
     model.rng, model.philox_seed = "philox", 1
+    model.philox_advance = False      # this test replays the same noise stream call after call
     y = model(x.to(U.DEV), img.to(U.DEV), feat.to(U.DEV), t=torch.as_tensor(10002))["diffusion_out"]
     assert torch.isfinite(y).all() and (y.sum(1) - 1).abs().max() < 1e-5
 
@@ -760,6 +757,7 @@ def test_c5_step_vs_reference_golden_g12(U, golden, parity_log):
     assert torch.isfinite(b).all() and (b.sum(1) - 1).abs().max() < 1e-5 and b.std() > 1e-3
     # two strided sampling steps of the shard with the device RNG
     model.rng, model.philox_seed = "philox", 3
+    model.philox_advance = False      # this test replays the same noise stream call after call
     y = model(x4.to(U.DEV), img4.to(U.DEV), t=torch.as_tensor(10002))["diffusion_out"]
     assert y.shape == (4, 20, 512, 1024) and torch.isfinite(y).all() and (y.sum(1) - 1).abs().max() < 1e-5
 
@@ -834,6 +832,7 @@ def test_c3_full_size_t1000(U, parity_log):
     parity_log("c3_n64_t1000_teacher_forced", max_dx0=worst, bar=1e-4)
     # ---- full T=1000 walk ----
     model.rng, model.philox_seed = "philox", 7
+    model.philox_advance = False      # this test replays the same noise stream call after call
     x = O.one_hot_bchw(torch.from_numpy(rng.integers(0, 2, (N, 128, 128))), 2).to(U.DEV)
     image = image.to(U.DEV)
     full = sample_sharded(model, x, image)                              # t=None: all 1000 steps
@@ -914,6 +913,7 @@ def test_substreams_do_not_change_the_samples(U, rng_mode):
     model.unet.load_state_dict({k: torch.from_numpy(v) for k, v in make_synthetic_state_dict(model.unet.spec, 3).items()}, strict=True)
     model = model.to(U.DEV).eval()
     model.prec, model.rng, model.philox_seed = hip.PREC_F16X3, rng_mode, 99
+    model.philox_advance = False      # this test replays the same noise stream call after call
     g = np.random.default_rng(5)
     img = torch.from_numpy(g.uniform(-1, 1, (N, 1, H, W)).astype(np.float32)).to(U.DEV)
     x = torch.nn.functional.one_hot(torch.from_numpy(g.integers(0, K, (N, H, W))), K).permute(0, 3, 1, 2).float().to(U.DEV)
@@ -938,6 +938,7 @@ def test_latency_slicing_mode_of_the_model(U, parity_log):
     model.unet.load_state_dict({k: torch.from_numpy(v) for k, v in make_synthetic_state_dict(model.unet.spec, 4).items()}, strict=True)
     model = model.to(U.DEV).eval()
     model.prec, model.rng, model.philox_seed = hip.PREC_F16X3, "philox", 5
+    model.philox_advance = False      # this test replays the same noise stream call after call
     g = np.random.default_rng(6)
     img = torch.from_numpy(g.uniform(-1, 1, (N, 1, H, W)).astype(np.float32)).to(U.DEV)
     x = torch.nn.functional.one_hot(torch.from_numpy(g.integers(0, K, (N, H, W))), K).permute(0, 3, 1, 2).float().to(U.DEV)
@@ -1113,6 +1114,7 @@ def test_dino_features_feed_the_sampler(U):
     model.unet.load_state_dict({k: torch.from_numpy(v) for k, v in make_synthetic_state_dict(model.unet.spec, 2).items()}, strict=True)
     model = model.to(U.DEV).eval()
     model.prec, model.rng = hip.PREC_F16X3, "philox"
+    model.philox_advance = False      # this test replays the same noise stream call after call
     enc = DinoViT(fce["model"], fce["train"], fce["conditioning"], stride=fce["output_stride"], state_dict=make_synthetic_vit_state_dict(seed=4))
     g = np.random.default_rng(9)
     img = torch.from_numpy(g.uniform(-1, 1, (N, 3, H, W)).astype(np.float32)).to(U.DEV)
@@ -1207,6 +1209,7 @@ def test_trained_like_weights_overflow_is_loud_and_falls_back(U, parity_log):
     assert err < 1e-4
     # the sampling loop takes the same route (and reproduces the all-fp32 samples: same Philox counters)
     model.prec, model.rng, model.philox_seed = hip.PREC_F16X3, "philox", 5
+    model.philox_advance = False      # this test replays the same noise stream call after call
     a = model(x.to(U.DEV), img.to(U.DEV), t=torch.as_tensor(10003))["diffusion_out"]
     model.prec = hip.PREC_F32
     b = model(x.to(U.DEV), img.to(U.DEV), t=torch.as_tensor(10003))["diffusion_out"]
@@ -1287,6 +1290,7 @@ for vote, rng_mode, gather in (("confidence", "philox", True), ("majority", "phi
     model.unet.load_state_dict({k: torch.from_numpy(v) for k, v in make_synthetic_state_dict(model.unet.spec, 0).items()}, strict=True)
     model = model.cuda().eval()
     model.rng, model.philox_seed = rng_mode, 11
+    model.philox_advance = False      # this test replays the same noise stream call after call
     torch.manual_seed(123)
     full = sample_sharded(model, x, img, t=torch.as_tensor(10004), gather=gather)
     assert full.shape == (N, 2, 128, 128)

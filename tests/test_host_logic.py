@@ -430,6 +430,7 @@ def test_host_noise_is_drawn_in_bounded_blocks(monkeypatch):
         def set_inputs(self, *a): pass
         def set_tables(self, *a): pass
         def raise_if_flagged(self): pass
+        def check_and_clear_flag(self): return False
         def run(self, n_steps, *, first_row, noise, noise_row0, **kw):
             calls.append((first_row, n_steps, noise_row0, None if noise is None else noise.clone()))
     monkeypatch.setattr(Mo.DenoisingModel, "_engine", lambda self, x, c, f, slot=0: Eng(x.shape[0]))
