@@ -40,6 +40,27 @@ static inline int exp_env(const char* name) { const char* v = getenv(name); retu
 static inline constexpr int exp_env(const char*) { return 0; }
 #endif
 
+// A kernel whose argument block spans several 64-byte lines fetches them where the compiler first needs a field — one scalar-cache
+// miss (a round trip to L2: hundreds of cycles) after another, at the top of a block whose dependent chain is the launch time
+// (few-pixel stages: one block per CU, every block misses).  This touches every line of a BYTES-long kernarg segment at once and
+// waits once: the misses overlap, the compiler's own loads hit.
+#ifdef __HIPCC__
+template <int BYTES>
+__device__ __forceinline__ void warm_kernargs() {
+    const auto kp = __builtin_amdgcn_kernarg_segment_ptr();
+    static_assert(BYTES <= 512, "eight lines");
+    constexpr int L = (BYTES + 63) / 64;                 // lines of the explicit arguments; a line index beyond them re-reads line 0
+    unsigned d0, d1, d2, d3, d4, d5, d6, d7;
+    // ONE statement: requests and the wait together, so that no destination register is handed out again while its load is in flight
+    asm volatile("s_load_dword %0, %8, %9\n\ts_load_dword %1, %8, %10\n\ts_load_dword %2, %8, %11\n\ts_load_dword %3, %8, %12\n\t"
+                 "s_load_dword %4, %8, %13\n\ts_load_dword %5, %8, %14\n\ts_load_dword %6, %8, %15\n\ts_load_dword %7, %8, %16\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(d0), "=&s"(d1), "=&s"(d2), "=&s"(d3), "=&s"(d4), "=&s"(d5), "=&s"(d6), "=&s"(d7)
+                 : "s"(kp), "i"(0), "i"(L > 1 ? 0x40 : 0), "i"(L > 2 ? 0x80 : 0), "i"(L > 3 ? 0xc0 : 0), "i"(L > 4 ? 0x100 : 0),
+                   "i"(L > 5 ? 0x140 : 0), "i"(L > 6 ? 0x180 : 0), "i"(L > 7 ? 0x1c0 : 0));
+}
+#endif
+
 // ---- conv launch geometry (shared by the kernel dispatcher, the packer and ccdm_conv_slices) ----
 struct ConvGeo {
     int TH, TW, waves, MI;   // output tile, waves per block, 32-pixel sub-tiles per wave

@@ -1133,6 +1133,12 @@ int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
         CCDM_CHECK_LAUNCH("conv1x1");
         return 0;
     }
+    if (!up2 && !a.fine_slices && conv_ks_eligible(a, k.slices)) {   // few-pixel images: K split over the waves, weight fragments straight from L2
+        const int rck = launch_conv_ks(a, k.slices, k.ntiles, k.wscale, s);
+        if (rck) return rck;
+        CCDM_CHECK_LAUNCH("conv_ks");
+        return 0;
+    }
     const int HP = ((g.TH - 1) * a.stride + a.ksize) * ((g.TW - 1) * a.stride + a.ksize);
     const int ck = chunk_ck(a, g);
     {   // wide skip chunks (k_conv, SKW): the wide-tile F16X3 one-n-tile variant, skip sources in multiples of 32 channels
@@ -1204,6 +1210,9 @@ extern "C" int ccdm_conv_slices_ex(int Hin, int Win, int ksize, int stride, int 
 
 extern "C" int ccdm_debug_read_timeline(unsigned long long* host, int n) {
     if (!host || n <= 0 || n > 1024) return ccdm::fail("debug_read_timeline: bad args");
+#ifdef CCDM_ABLATION
+    if (ccdm::conv_ks_timeline_read(host, n)) return 0;
+#endif
 #ifdef CCDM_EXPERIMENTS
     if (ccdm::conv_pc_timeline_read(host, n)) return 0;
 #endif

@@ -60,6 +60,13 @@ struct ConvK {   // kernel-side copy of ccdm_conv_args (+ derived)
 bool conv1x1_eligible(const ccdm_conv_args& a, int slices);
 int launch_conv1x1(const ccdm_conv_args& a, int slices, int ntiles, const float* wscale, hipStream_t s);
 
+// 3x3 conv of a few-pixel image, K split over the waves of a block, weight fragments straight from L2 (ccdm_conv_ks.hip)
+bool conv_ks_eligible(const ccdm_conv_args& a, int slices);
+int launch_conv_ks(const ccdm_conv_args& a, int slices, int ntiles, const float* wscale, hipStream_t s);
+#ifdef CCDM_ABLATION
+bool conv_ks_timeline_read(unsigned long long* host, int n);
+#endif
+
 #ifdef CCDM_EXPERIMENTS
 // producer/consumer form of the full-width 3x3 stages (tools/experiments/ccdm_conv_pc.hip: measured slower, never in the shipped library)
 bool conv_pc_eligible(const ConvK& k, const ConvGeo& g, int NI);

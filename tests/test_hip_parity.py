@@ -181,7 +181,7 @@ def test_conv_latency_slicing(U, c0, cout, H, W, k, stride, up):
         np.testing.assert_allclose(yb.cpu().numpy(), ya.cpu().numpy(), rtol=0, atol=2e-6)
     if (H, W, k) == (16, 16, 3):
         # latency slicing also re-tiles 16x16 images (8x8 tiles, kernel rows split over three wave groups): another summation order
-        np.testing.assert_allclose(fine.cpu().numpy(), base.cpu().numpy(), rtol=0, atol=4e-6)
+        np.testing.assert_allclose(fine.cpu().numpy(), base.cpu().numpy(), rtol=0, atol=8e-6)
     else:
         assert torch.equal(base, fine)
     assert st1.shape[1] >= st0.shape[1] and st1.shape[1] <= hip.STATS_MAX_SLICES
@@ -279,6 +279,64 @@ def test_conv_with_fused_skip(U, prec, c0, c1, cout, H, W):
     np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=0, atol=3e-5)
     gd = got.double()
     np.testing.assert_allclose(ost.cpu().sum(1)[..., 0].numpy(), gd.sum((2, 3)).numpy(), rtol=0, atol=2e-6 * gd.abs().sum((2, 3)).max().item())
+
+
+# few-pixel images (H, W multiples of 8, at most 128 pixels) run ccdm_conv_ks.hip: K split over the waves of a block, weight fragments
+# straight from L2.  (cin0, cin1, cout, H, W, k, stride, up, gn, act, emb, resid) as in CONV_CASES — H, W are the INPUT size.
+CONV_KS_CASES = [
+    (128, 0, 128, 8, 8, 3, 1, 0, 1, 1, 1, 0),      # ResBlock.in_layers at the 8x8 stage (+ emb)
+    (128, 0, 128, 8, 8, 3, 1, 0, 1, 1, 0, 1),      # out_layers + identity residual
+    (128, 128, 128, 8, 8, 3, 1, 0, 1, 1, 1, 0),    # decoder: 256 channels over a concat seam, two fragment batches per wave
+    (128, 96, 128, 8, 8, 3, 1, 0, 1, 1, 1, 0),     # 224 = 128 + 96: 7 channels per group straddling the seam
+    (96, 0, 128, 16, 16, 3, 2, 0, 0, 0, 0, 0),     # Downsample 16x16 -> 8x8 (17x17 halo, stride-2 fragment walk)
+    (64, 0, 64, 16, 32, 3, 2, 0, 0, 0, 0, 0),      # Downsample to 8x16: two tiles per sample
+    (64, 0, 64, 8, 16, 3, 1, 0, 1, 1, 0, 1),       # 64 channels: four staged pixels per wave item, two tiles
+    (32, 0, 32, 16, 8, 3, 1, 0, 1, 1, 1, 1),       # 32 channels: half of the 16 lanes per pixel idle
+    (48, 16, 32, 8, 8, 3, 1, 0, 0, 1, 0, 0),       # SiLU without GroupNorm, seam inside a 16-channel k-step
+    (20, 0, 32, 8, 8, 3, 1, 0, 0, 0, 0, 1),        # 20 channels padded to 32: the padded quads must be staged as zeros
+    (160, 0, 96, 8, 8, 3, 1, 0, 1, 1, 0, 0),       # 160 channels: 40 of 64 lanes per pixel
+]
+
+
+@pytest.mark.parametrize("case", CONV_KS_CASES, ids=lambda c: "-".join(map(str, c)))
+def test_conv_few_pixel_kernel(U, case):
+    """ccdm_conv_ks.hip against torch (through test_conv) and against the general kernel on the same inputs (CCDM_DIAG_GENERAL_KERNEL):
+    same products, another summation order over K — equal to fp32 rounding, statistics likewise."""
+    test_conv(U, case, hip.PREC_F16X3)
+    c0, c1, cout, H, W, k, stride, up, gn, act, emb, resid = case
+    rng = np.random.default_rng(sum(case) + 1)
+    N = 3
+    xa = rnd(rng, N, c0, H, W) * 1.5 + 0.3
+    xb = rnd(rng, N, c1, H, W) * 0.7 - 0.2 if c1 else None
+    w = rnd(rng, cout, c0 + c1, 3, 3) / np.sqrt((c0 + c1) * 9)
+    b = rnd(rng, cout, scale=0.1)
+    gamma, beta = 1 + rnd(rng, c0 + c1, scale=0.1), rnd(rng, c0 + c1, scale=0.1)
+    srcs = [U.nhwc(xa)] + ([U.nhwc(xb)] if c1 else [])
+    stats = [U.gn_stats(s_, 2) for s_ in srcs] if gn else None
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    res = U.nhwc(rnd(rng, N, cout, Ho, Wo)) if resid else None
+    embt = rnd(rng, N, cout).numpy() if emb else None
+    kw = dict(stats=stats, gamma=gamma.numpy(), beta=beta.numpy(), act=hip.ACT_SILU if act else hip.ACT_NONE, stride=stride,
+              emb=embt, emb_rows=np.arange(N) if emb else None, resid=res, prec=hip.PREC_F16X3)
+    out, ost = U.conv2d(srcs, w.numpy(), b.numpy(), 3, **kw)
+    gen, gst = U.conv2d(srcs, w.numpy(), b.numpy(), 3, diag=hip.DIAG_GENERAL_KERNEL, **kw)
+    np.testing.assert_allclose(out.cpu().numpy(), gen.cpu().numpy(), rtol=0, atol=8e-6)
+    np.testing.assert_allclose(ost.sum(1).cpu().numpy(), gst.sum(1).cpu().numpy(), rtol=2e-6, atol=1e-4)
+    again, ast_ = U.conv2d(srcs, w.numpy(), b.numpy(), 3, **kw)
+    assert torch.equal(out, again) and torch.equal(ost, ast_), "run-to-run nondeterminism"
+    # batch-shard invariance: the last sample alone reproduces its slice bit for bit
+    kw1 = dict(kw, stats=[s_[N - 1:] for s_ in stats] if gn else None, emb=embt[N - 1:] if emb else None, emb_rows=np.arange(1) if emb else None,
+               resid=res[N - 1:].contiguous() if resid else None)
+    one, ost1 = U.conv2d([s_[N - 1:].contiguous() for s_ in srcs], w.numpy(), b.numpy(), 3, **kw1)
+    assert torch.equal(one, out[N - 1:]) and torch.equal(ost1, ost[N - 1:])
+
+
+@pytest.mark.parametrize("c0,c1,cout,H,W", [(256, 0, 128, 8, 8), (128, 96, 128, 8, 8), (128, 128, 128, 8, 16), (64, 32, 64, 16, 8), (32, 0, 64, 8, 8),
+                                             (160, 0, 96, 8, 8)])
+def test_conv_few_pixel_kernel_fused_skip(U, c0, c1, cout, H, W):
+    """decoder ResBlock tail at the deepest levels: the fused 1x1 skip segment as extra K steps of ccdm_conv_ks.hip (raw input, 64 core
+    pixels staged behind the halo tile)"""
+    test_conv_with_fused_skip(U, hip.PREC_F16X3, c0, c1, cout, H, W)
 
 
 def test_conv_rejects_bad_args(U):

@@ -31,4 +31,13 @@ if __name__ == "__main__":
     for slot, t in ev[1:]:
         out.append(f"{NAMES.get(slot, slot)}+{t - prev}")
         prev = t
+    if os.environ.get("CCDM_TIMELINE_KS"):      # ccdm_conv_ks.hip's stamps
+        NAMES.clear()
+        NAMES.update({1: "entry", 2: "halo-issued", 3: "B+epi-issued", 4: "gn-table", 5: "commit", 6: "barrier", 7: "mfma", 8: "barrier", 9: "partials+barrier",
+                      10: "reduce+store", 11: "stats"})
+        out = []
+        prev = ev[0][1]
+        for slot, t in ev[1:]:
+            out.append(f"{NAMES.get(slot, slot)}+{t - prev}")
+            prev = t
     print(f"op {os.environ.get('CCDM_TIMELINE_OP')}: total {prev - ev[0][1]} cycles: " + " ".join(out[:80]))
