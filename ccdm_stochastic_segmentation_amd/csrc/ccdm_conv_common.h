@@ -207,8 +207,19 @@ __device__ __forceinline__ void gn_prefetch(const ccdm_conv_args& a, bool has_gn
     const char* base = static_cast<const char*>(dummy);
     if (has_gn) base = gn_channel_row(a, n, c, S, stride);               // uniform condition, selects only
     const unsigned last = (unsigned)(S - 1) * stride, first = (unsigned)(16 * grp) * stride;
+    // Few-pixel images leave 1-4 slices: 12 of the 16 requests would be clamped duplicates — 1 KB per wave each through a vector-memory
+    // front end that takes ~40-64 B/clk, ~800 cycles of every block's prologue ahead of its halo request.  The slice count is a kernel
+    // argument (uniform), so the extra requests sit behind one scalar branch.
+    const bool few = !has_gn || (a.slices0 <= 4 && a.slices1 <= 4);
 #pragma unroll
-    for (int u = 0; u < 16; ++u) g.v[u] = *reinterpret_cast<const f64x2*>(base + min(first + (unsigned)u * stride, last));
+    for (int u = 0; u < 4; ++u) g.v[u] = *reinterpret_cast<const f64x2*>(base + min(first + (unsigned)u * stride, last));
+    if (!few) {
+#pragma unroll
+        for (int u = 4; u < 16; ++u) g.v[u] = *reinterpret_cast<const f64x2*>(base + min(first + (unsigned)u * stride, last));
+    } else {
+#pragma unroll
+        for (int u = 4; u < 16; ++u) g.v[u] = f64x2{0.0, 0.0};
+    }
 }
 // (sum, sum^2) of channel c over the slices [16 grp, 16 grp + 16) from the prefetched values g (NULL: fetched here), ascending; the lane
 // of group 0 also takes the slices beyond 16 G (more slices than one prefetch round of the block covers: blocking loads)

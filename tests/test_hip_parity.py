@@ -459,7 +459,7 @@ def test_posterior_matches_oracle_and_reference_golden(U, golden, K):
 
 
 @pytest.mark.parametrize("K", [2, 20])
-def test_sampler_bit_exact_on_reference_golden(U, golden, K):
+def test_sampler_bit_exact_on_reference_golden(U, golden, K, parity_log):
     """Same posterior probabilities + same noise -> identical class indices (T2 steps 2-4).  The kernel is
     driven with a = 0, c = 1 (t == 1 coefficients: posterior == its input) and softmax off, so its input
     *is* the posterior the reference sampled from."""
@@ -486,7 +486,8 @@ def test_sampler_bit_exact_on_reference_golden(U, golden, K):
         assert torch.equal(idx, r["xt_next"].reshape(N, H, W).long())
         # and may differ from the reference only where the race is a near-tie (last-ulp normalisation order)
         diff = (idx.numpy() != g[f"K{K}_idx"])
-        assert diff.mean() < 0.01
+        parity_log(f"g6_sampler_K{K}", index_mismatch_vs_reference=diff.mean(), pixels=diff.size)
+        assert diff.mean() <= 2.0 / diff.size + FREE_RUN_FRAC       # (measured 0; a near-tie of the last-ulp normalisation order may flip a pixel)
 
 
 def test_philox_stream_matches_oracle(U):
@@ -578,14 +579,83 @@ def test_trajectory_teacher_forced_and_free_running(U, golden, lidc_model, parit
             frac = (err > 1e-3).mean()
             print(f"free-running: median|dp|={np.median(err):.2e} frac>1e-3={frac:.2e}")
             parity_log(f"g7_trajectory[prec={model.prec}]", free_running_median_dp=np.median(err), free_running_frac_gt_1e3=frac)
-            assert np.median(err) < 1e-5 and frac < 0.02
+            assert np.median(err) < 1e-6 and frac <= FREE_RUN_FRAC
         else:
             assert out.dtype == torch.int64
             mism = (out.argmax(1).numpy() != unpack(g["out_majority"], (2, 128, 128))).mean()
             print(f"free-running majority mismatch rate = {mism:.2e}")
             parity_log(f"g7_trajectory[prec={model.prec}]", free_running_majority_mismatch=mism)
-            assert mism < 0.02
+            assert mism <= FREE_RUN_FRAC
     model.step_T_sample = "confidence"
+
+
+# Free-running bounds.  A seeded free-running walk can only leave the reference's where a draw is a near-tie: argmax_k p_k / E_k flips when
+# two classes' ratios agree to ~1e-6 relative (the kernels match the reference's probabilities to ~2e-6), which has probability
+# ~1e-6 per pixel and step; one flipped pixel then perturbs later steps inside its receptive field.  Measured (profiles/
+# r03_parity_report.json): 0 flips, 0 pixels beyond 1e-3 on every seeded walk of this suite (K = 2 and K = 20).  The bounds below
+# allow a handful of such events (4 of 32 768 pixels), two orders below the 1-2 % of earlier rounds.
+FREE_RUN_FRAC = 1.25e-4
+
+
+def test_trajectory_k20_teacher_forced_and_free_running(U, golden, parity_log):
+    """G15 (tools/gen_goldens_k20.py): the reference's seeded 10-step strided walk at K = 20 with DINO features (64x128, N = 2) — where
+    its own normalisation order is position-dependent.  Teacher-forced: every step's network output within 1e-4 of the reference's and,
+    given the reference's x_t and the same host noise, the drawn class map equal to the reference's next x_t; free-running (parity RNG):
+    final class map and probabilities."""
+    from tests.test_oracle_golden import k20_case
+    g = golden["g15_trajectory_k20"]
+    spec, sd, img, feat = k20_case()
+    fce = dict(type="dino", channels=384, output_stride=8, scale="single", target_layer=10)
+    model = build_model(250, "cosine", {"s": 0.008}, [(3, 64, 128), (20, 64, 128)], (3, 64, 128), "unet_openai",
+                        dict(LIDC_BP, channel_mult=[1, 1, 2, 2, 4, 4]), "datasets.cityscapes", "confidence", fce)
+    model.unet.load_state_dict(sd, strict=True)
+    model = model.to("cuda:0").eval()
+    N, K, H, W = 2, 20, 64, 128
+    t_values = [int(t) for t in g["t_values"]]
+    torch.manual_seed(7)
+    host_rng_ok = np.array_equal(torch.empty(64).exponential_(1).numpy(), golden["g6_sampler"]["exp_stream_seed7"])
+    sched = O.make_schedule("cosine", 250, {"s": 0.008})
+    # the reference's host noise: seed 42, the x_T draw, then one [N*H*W, K] block per step with t > 1
+    torch.manual_seed(42)
+    xT, _ = O.draw_x_T(N, K, H, W)
+    assert np.array_equal(xT.numpy(), g["xT"])
+    worst, flips = 0.0, 0.0
+    for j, t in enumerate(t_values):
+        xt = torch.from_numpy(g[f"xt_{j}"].astype(np.int64))
+        out = model(O.one_hot_bchw(xt, K).to(U.DEV), img.to(U.DEV), feat.to(U.DEV), t=torch.full((N,), float(t)), validation=True)["diffusion_out"]
+        worst = max(worst, np.abs(out.cpu()[:, :, ::8, ::8].numpy() - g[f"x0pred_lattice_{j}"]).max())
+        if t > 1:
+            e = torch.empty(N * H * W, K).exponential_(1)
+            a, c = O.posterior_coeffs(sched[1], sched[2], t)
+            r = U.posterior_sample(U.nhwc(out.cpu()).reshape(N, H * W, K), xt.to(torch.uint8).reshape(N, -1).to(U.DEV), a, c, hip.STEP_SAMPLE,
+                                   softmax=False, noise=e.reshape(N, -1).contiguous().to(U.DEV))
+            if host_rng_ok:
+                flips = max(flips, (r["xt_next"].reshape(N, H, W).numpy() != g[f"xt_{j + 1}"]).mean())
+    print(f"K=20 teacher-forced: max|d x0pred| = {worst:.3e}, worst per-step draw mismatch = {flips:.2e}")
+    parity_log("g15_trajectory_k20", teacher_forced_max_dx0=worst, teacher_forced_draw_mismatch=flips, bar=1e-4)
+    assert worst < 1e-4 and flips <= FREE_RUN_FRAC
+    if not host_rng_ok:
+        pytest.skip("host exponential_ stream differs from the fixture host; seeded trajectory not comparable")
+    from ccdm_stochastic_segmentation_amd import OneHotCategoricalBCHW
+    for vote in ("confidence", "majority"):
+        model.step_T_sample, model.rng = vote, "torch_cpu"
+        torch.manual_seed(42)
+        x = OneHotCategoricalBCHW(logits=torch.zeros(N, K, H, W)).sample()
+        out = model(x.to(U.DEV), img.to(U.DEV), feat.to(U.DEV), t=torch.as_tensor(10010))["diffusion_out"].cpu()
+        if vote == "confidence":
+            assert out.dtype == torch.float32 and tuple(out.stride()) == tuple(g["out_stride"])
+            mism = (out.argmax(1).numpy() != g["out_argmax"]).mean()
+            err = np.abs(out[:, :, ::4, ::4].numpy() - g["out_lattice"])
+            frac = (err > 1e-3).mean()
+            dsum = np.abs(out.double().sum((2, 3)).numpy() - g["out_class_sums"]).max()
+            print(f"K=20 free-running: argmax mismatch {mism:.2e}, lattice max|dp| {err.max():.2e}, frac>1e-3 {frac:.2e}, class sums {dsum:.2e}")
+            parity_log("g15_trajectory_k20", free_running_argmax_mismatch=mism, free_running_max_dp_lattice=err.max(), free_running_frac_gt_1e3=frac)
+            assert mism <= FREE_RUN_FRAC and frac <= FREE_RUN_FRAC and np.median(err) < 1e-6
+        else:
+            assert out.dtype == torch.int64
+            mism = (out.argmax(1).numpy() != g["out_majority"]).mean()
+            parity_log("g15_trajectory_k20", free_running_majority_mismatch=mism)
+            assert mism <= FREE_RUN_FRAC
 
 
 def test_caller_contract_g9(U, golden, lidc_model):
@@ -604,7 +674,7 @@ def test_caller_contract_g9(U, golden, lidc_model):
     pred = pred.reshape(labels.shape[0], -1, *labels.shape[2:])
     assert list(pred.shape) == list(g["shape"])
     err = np.abs(pred[:, :, 0].cpu().numpy() - g["pred_c0"])
-    assert np.median(err) < 1e-5 and (err > 1e-3).mean() < 0.02
+    assert np.median(err) < 1e-6 and (err > 1e-3).mean() <= FREE_RUN_FRAC
 
 
 @pytest.mark.parametrize("prec", PRECS, ids=PREC_IDS)
@@ -946,7 +1016,7 @@ def test_c4_n16_two_strided_steps_vs_oracle(U, parity_log):
     print(f"C4 N=16 two strided steps, samples 0 and 15: median|dp|={d.median().item():.2e} frac>1e-3={frac:.2e}")
     parity_log("c4_n16_two_steps_vs_oracle", first_step_max_dp=err, free_running_median_dp=d.median().item(), free_running_frac_gt_1e3=frac, bar=1e-4)
     assert (out.sum(1) - 1).abs().max() < 1e-5 and torch.isfinite(out).all()
-    assert d.median().item() < 1e-5 and frac < 0.02
+    assert d.median().item() < 1e-6 and frac <= FREE_RUN_FRAC
 
 
 @pytest.mark.gpu
@@ -1326,7 +1396,7 @@ def test_softmax_output_off_and_ce_head(U, parity_log):
     oref = O.forward_denoising(sd, dict(LIDC_CFG, softmax_output=False, ce_head=True), O.make_schedule("cosine", 50, {"s": 0.008}), x, img, None, 2,
                                "confidence")["diffusion_out"]
     d = (out - oref).abs()
-    assert d.median().item() < 1e-5 and (d > 1e-3).float().mean().item() < 0.02
+    assert d.median().item() < 1e-6 and (d > 1e-3).float().mean().item() <= FREE_RUN_FRAC
 
 
 # ------------------------------------------------------------------------------------------ two ranks of the REAL model
@@ -1529,3 +1599,31 @@ def test_attention_stress_mfma_vs_valu(U, parity_log):
             else:
                 assert torch.equal(got, first), f"launch {it} of {(N, T, Ta, C, heads, order)} differs from the first"
     parity_log("attention_stress_mfma_vs_valu", launches=iters * len(cases), max_abs_diff_vs_valu=worst)
+
+
+@pytest.mark.gpu
+def test_philox_stream_advances_per_call(U):
+    """DenoisingModel.philox_call: successive sampling calls draw independent noise (the batches of an evaluation loop must not replay
+    one stream); setting the counter back replays a call bit for bit; the key does not depend on how the batch is split."""
+    model = build_model(250, "cosine", {"s": 0.008}, [(1, 128, 128), (2, 128, 128)], (1, 128, 128), "unet_openai", LIDC_BP,
+                        "datasets.lidc", "confidence", None)
+    sd = {k: torch.from_numpy(v) for k, v in make_synthetic_state_dict(model.unet.spec, 0).items()}
+    model.unet.load_state_dict(sd, strict=True)
+    model = model.to("cuda:0").eval()
+    assert model.rng == "philox" and model.philox_advance and model.philox_call == 0
+    rng = np.random.default_rng(2)
+    N = 4
+    image = torch.from_numpy(rng.uniform(-1, 1, (N, 1, 128, 128)).astype(np.float32)).to(U.DEV)
+    x = O.one_hot_bchw(torch.from_numpy(rng.integers(0, 2, (N, 128, 128))), 2).to(U.DEV)
+    t = torch.as_tensor(10004)
+    a = model(x, image, t=t)["diffusion_out"].clone()
+    b = model(x, image, t=t)["diffusion_out"].clone()
+    assert model.philox_call == 2
+    assert (a - b).abs().max() > 1e-3, "two calls replayed the same noise stream"
+    model.philox_call = 0
+    assert torch.equal(model(x, image, t=t)["diffusion_out"], a)
+    model.philox_call, model.sample_offset = 1, 2            # call 1 again, as the shard holding samples 2..3
+    part = model(x[2:], image[2:], t=t)["diffusion_out"]
+    model.sample_offset = 0
+    assert torch.equal(part, b[2:])
+    assert len({model._philox_key() for model.philox_call in range(64)}) == 64

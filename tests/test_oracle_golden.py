@@ -184,6 +184,47 @@ def test_g8_dino_step(golden):
     np.testing.assert_allclose(out["diffusion_out"].numpy(), g["out"], rtol=0, atol=1e-6)
 
 
+def k20_case():
+    """the G15 workload (tools/gen_goldens_k20.py): the G8 network, N = 2, 64x128, K = 20, DINO features"""
+    fce = dict(type="dino", channels=384, output_stride=8, scale="single", target_layer=10)
+    spec = make_unet_spec(image_size=64, in_channels=23, out_channels=20, feature_cond_encoder=fce,
+                          **dict(LIDC_BP, channel_mult=[1, 1, 2, 2, 4, 4]))
+    sd = {k: torch.from_numpy(v) for k, v in make_synthetic_state_dict(spec, 8).items()}
+    rng = np.random.default_rng(15)
+    img = torch.from_numpy(rng.standard_normal((2, 3, 64, 128)).astype(np.float32))
+    feat = torch.from_numpy(rng.standard_normal((2, 384, 8, 16)).astype(np.float32))
+    return spec, sd, img, feat
+
+
+def test_g15_trajectory_k20(golden):
+    """K = 20 free-running, 10 strided steps, seed 42, DINO features (the reference's own normalisation order is position-dependent for
+    K > 4): the oracle's seeded walk reproduces the reference's per-step class maps and final outputs."""
+    g = golden["g15_trajectory_k20"]
+    _, sd, img, feat = k20_case()
+    cfg = dict(LIDC_CFG, feature_condition_idx=[10])
+    sched = O.make_schedule("cosine", 250, {"s": 0.008})
+    for vote in ("confidence", "majority"):
+        torch.manual_seed(42)
+        idx, _ = O.draw_x_T(2, 20, 64, 128)
+        assert np.array_equal(idx.numpy(), g["xT"])
+        trace = []
+        out = O.forward_denoising(sd, cfg, sched, O.one_hot_bchw(idx, 20), img, feat, 10010, vote, trace=trace)["diffusion_out"]
+        assert [r["t"] for r in trace] == list(g["t_values"])
+        xt = idx
+        for j, r in enumerate(trace):
+            assert np.array_equal(xt.numpy(), g[f"xt_{j}"]), f"x_t differs at step {j}"
+            np.testing.assert_allclose(r["x0pred"][:, :, ::8, ::8].numpy(), g[f"x0pred_lattice_{j}"], atol=2e-6)
+            if "idx" in r:
+                xt = r["idx"]
+        if vote == "confidence":
+            assert out.dtype == torch.float32 and tuple(out.stride()) == tuple(g["out_stride"])
+            assert np.array_equal(out.argmax(1).numpy(), g["out_argmax"])
+            np.testing.assert_allclose(out[:, :, ::4, ::4].numpy(), g["out_lattice"], atol=2e-6)
+            np.testing.assert_allclose(out.double().sum((2, 3)).numpy(), g["out_class_sums"], rtol=1e-6)
+        else:
+            assert out.dtype == torch.int64 and np.array_equal(out.argmax(1).numpy(), g["out_majority"])
+
+
 def test_g9_caller_reenactment(golden):
     """evaluate_lidc_uncertainty.py:93-103: repeat_interleave ordering, x_T from the host generator,
     [B_img, S, K, H, W] reshape."""
