@@ -1,5 +1,9 @@
-// Self-attention core on the matrix cores: head width 32 (every reference U-Net config: num_head_channels: 32) and 64 (the DINO
-// ViT-S/8 feature encoder, whose token rows may be padded: Ta rows allocated per sample, T of them tokens).
+// Self-attention core on the matrix cores: head width 32 (every shipped reference config: num_head_channels: 32), 64 (the DINO
+// ViT-S/8 feature encoder, whose token rows may be padded: Ta rows allocated per sample, T of them tokens) and, round 3, ANY head
+// width that is a multiple of 4 up to 128 — `create_unet_openai`'s own defaults are num_heads=1, num_head_channels=-1
+// (unet_openai/__init__.py:14-15, heads rule unet.py:283-289), i.e. one head as wide as the block (96 / 128 channels at the LIDC
+// widths), and num_heads=4 gives 24.  The kernel is instantiated for the padded widths DP in {32, 64, 96, 128}; a narrower head
+// (D < DP) stages zeros in the missing columns of K, Q and V (they add nothing to a score, and their output rows are not stored).
 //
 //   softmax((q*s)(k*s)^T) v   per (sample, head),   s = 32^-1/4        unet.py:343-360 (legacy) / :376-395 (new order)
 //
@@ -53,21 +57,24 @@ __device__ __forceinline__ void split8_frag(const float* v, f16x8& hi, f16x8& lo
     lo = __builtin_bit_cast(f16x8, l);
 }
 
-template <int WAVES, int D>
+// D = the padded head width the instantiation is laid out for; Dr = the head's real width (EXACT: Dr == D, the tuned round-2 code path)
+template <int WAVES, int D, bool EXACT = true>
 __global__ __launch_bounds__(WAVES * 64) void k_attention_mfma(const float* __restrict__ qkv, float* __restrict__ out,
-                                                              int T, int Ta, int C, int order) {
+                                                              int T, int Ta, int C, int order, int Dr_) {
     constexpr int NT = WAVES * 64, KROW = KRow<D>::B, DS = D / 16 /* 16-wide k-steps over d */, DM = D / 32 /* 32-row tiles of d */;
     constexpr int NPL = D / 16, VLO = NPL * VPLANE;                // V planes; byte offset of the lo image
-    __shared__ __attribute__((aligned(16))) char kt[KT * KROW];
-    __shared__ __attribute__((aligned(16))) char vt[2 * NPL * VPLANE];
+    extern __shared__ __attribute__((aligned(16))) char smem_attn[];       // dynamic: the 128-wide layout needs 68.6 KB
+    char* const kt = smem_attn;                                             // [KT * KROW]
+    char* const vt = smem_attn + KT * KROW;                                 // [2 * NPL * VPLANE]
+    const int Dr = EXACT ? D : Dr_;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = blockIdx.y, n = blockIdx.z;
     const int q0 = (blockIdx.x * WAVES + wave) * 32;
     const int C3 = 3 * C;
     int qoff, koff, voff;
-    if (order == 0) { qoff = h * 3 * D; koff = qoff + D; voff = qoff + 2 * D; }
-    else { qoff = h * D; koff = C + h * D; voff = 2 * C + h * D; }
-    const float scale = (float)(1.0 / sqrt(sqrt((double)D)));
+    if (order == 0) { qoff = h * 3 * Dr; koff = qoff + Dr; voff = qoff + 2 * Dr; }
+    else { qoff = h * Dr; koff = C + h * Dr; voff = 2 * C + h * Dr; }
+    const float scale = (float)(1.0 / sqrt(sqrt((double)Dr)));
     // scores are kept in units of log2(e): softmax(s) = 2^(s' - max s') / sum with s' = s * log2(e), so every exponential is one
     // v_exp_f32 with no multiply in front of it; the factor rides in the (already scaled) query
     const float qscale = scale * 1.4426950408889634f;
@@ -80,9 +87,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_attention_mfma(const float* __re
         const int tq = min(q0 + qi, T - 1);
 #pragma unroll
         for (int s = 0; s < DS; ++s) {
-            const float* p = base + (size_t)tq * C3 + qoff + 16 * s + 8 * half;
-            const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
-            const float v[8] = {a.x * qscale, a.y * qscale, a.z * qscale, a.w * qscale, b.x * qscale, b.y * qscale, b.z * qscale, b.w * qscale};
+            const int d0 = 16 * s + 8 * half;
+            // (a narrower head: columns beyond Dr are zeros; the clamped addresses stay inside the row)
+            const float* p = base + (size_t)tq * C3 + qoff + (EXACT ? d0 : min(d0, Dr - 4));
+            const float* p4 = base + (size_t)tq * C3 + qoff + (EXACT ? d0 + 4 : min(d0 + 4, Dr - 4));
+            const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p4);
+            const float sa = EXACT || d0 < Dr ? qscale : 0.f, sb = EXACT || d0 + 4 < Dr ? qscale : 0.f;
+            const float v[8] = {a.x * sa, a.y * sa, a.z * sa, a.w * sa, b.x * sb, b.y * sb, b.z * sb, b.w * sb};
             split8_frag(v, qh[s], ql[s]);
         }
     }
@@ -103,7 +114,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_attention_mfma(const float* __re
 #pragma unroll
         for (int u = 0; u < NSTG; ++u) {
             const int item = tid + u * NT;
-            const int key = min(j0 + item / (D / 4), T - 1), c4 = item % (D / 4);
+            const int key = min(j0 + item / (D / 4), T - 1), c4 = EXACT ? item % (D / 4) : min(item % (D / 4), (Dr >> 2) - 1);
             const float* p = base + (size_t)key * C3;
             pk[u] = *reinterpret_cast<const stage_t*>(p + koff + 4 * c4);
             pv[u] = *reinterpret_cast<const stage_t*>(p + voff + 4 * c4);
@@ -120,8 +131,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_attention_mfma(const float* __re
         for (int u = 0; u < NSTG; ++u) {
             const int item = tid + u * NT;
             const int key = item / (D / 4), c4 = item % (D / 4);
-            const bool in = j0 + key < T;
-            const float ks = in ? scale : 0.f, vs = in ? 1.f : 0.f;        // rows beyond T are staged as zeros
+            const bool in = j0 + key < T && (EXACT || 4 * c4 < Dr);
+            const float ks = in ? scale : 0.f, vs = in ? 1.f : 0.f;        // rows beyond T (and columns beyond a narrower head) are staged as zeros
             u32x2 hi, lo;
             unsigned a, b;
             split2_f16(sget(pk[u], 0) * ks, sget(pk[u], 1) * ks, a, b); hi[0] = a; lo[0] = b;
@@ -220,34 +231,73 @@ __global__ __launch_bounds__(WAVES * 64) void k_attention_mfma(const float* __re
     if (q0 + qi < T) {
         const float inv = 1.0f / l;
         // o[r] = O[query = lane&31][d = (r&3) + 8*(r>>2) + 4*half]: four float4 rows of 4 consecutive d each
-        float* dst = out + ((size_t)n * Ta + q0 + qi) * C + h * D + 4 * half;
+        float* dst = out + ((size_t)n * Ta + q0 + qi) * C + h * Dr + 4 * half;
 #pragma unroll
         for (int mt = 0; mt < DM; ++mt)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
-                *reinterpret_cast<float4*>(dst + 32 * mt + 8 * g) =
-                    make_float4(o[mt][4 * g] * inv, o[mt][4 * g + 1] * inv, o[mt][4 * g + 2] * inv, o[mt][4 * g + 3] * inv);
+                if (EXACT || 32 * mt + 8 * g + 4 * half < Dr)
+                    *reinterpret_cast<float4*>(dst + 32 * mt + 8 * g) =
+                        make_float4(o[mt][4 * g] * inv, o[mt][4 * g + 1] * inv, o[mt][4 * g + 2] * inv, o[mt][4 * g + 3] * inv);
     }
+}
+
+template <int WAVES, int DP, bool EXACT>
+static void launch_attn_inst(dim3 grid, hipStream_t s, const float* qkv, float* out, int T, int Ta, int C, int order, int D) {
+    constexpr size_t lds = (size_t)KT * KRow<DP>::B + (size_t)2 * (DP / 16) * VPLANE;
+    hipLaunchKernelGGL((k_attention_mfma<WAVES, DP, EXACT>), grid, dim3(WAVES * 64), lds, s, qkv, out, T, Ta, C, order, D);
+}
+
+// padded head width the MFMA kernel runs a head of width D on (0: none — D not a multiple of 4, or beyond 128)
+int attention_mfma_width(int D) {
+    if (D <= 0 || D % 4 || D > 128) return 0;
+    return D <= 32 ? 32 : (D <= 64 ? 64 : (D <= 96 ? 96 : 128));
 }
 
 int launch_attention_mfma(const float* qkv, float* out, int N, int T, int Ta, int C, int heads, int order, hipStream_t s) {
     const int D = C / heads;
+    const int DP = attention_mfma_width(D);
+    CCDM_REQUIRE(DP > 0, "attention_mfma: head width %d (C=%d, heads=%d) is not a multiple of 4 up to 128", D, C, heads);
     // 8 waves (256 queries) per block for long sequences at head width 32: a key tile's staging (split to fp16 hi/lo, LDS writes) is
     // shared by twice as many queries — one item per thread instead of two
     // (T = 8192, N = 4, 4 heads: 570 -> 502 us = 29.0 -> 32.8 % of the fp16 matrix peak by instruction count; T = 2048: 90 -> 83 us)
     const int w8_env = exp_env("CCDM_ATTN_W8_MIN");      // A/B hook of CCDM_EXPERIMENTS builds (-1: never)
     const int w8_min = w8_env ? w8_env : 2048;
-    const int waves = (D == 32 && w8_min > 0 && T >= w8_min) ? 8 : (T >= 128 ? 4 : (T >= 64 ? 2 : 1));
+    int waves = (DP == 32 && w8_min > 0 && T >= w8_min) ? 8 : (T >= 128 ? 4 : (T >= 64 ? 2 : 1));
+    // wide heads: the staged K/V items and the query fragments of a wave grow with the width — keep them inside the register file by
+    // spreading a key tile over more threads (96: at least 4 waves; 128: always 8)
+    if (DP == 96 && waves < 4) waves = 4;
+    if (DP == 128) waves = 8;
     dim3 grid(cdiv(T, 32 * waves), heads, N);
-    if (D == 64) {
-        if (waves == 4) hipLaunchKernelGGL((k_attention_mfma<4, 64>), grid, dim3(256), 0, s, qkv, out, T, Ta, C, order);
-        else if (waves == 2) hipLaunchKernelGGL((k_attention_mfma<2, 64>), grid, dim3(128), 0, s, qkv, out, T, Ta, C, order);
-        else hipLaunchKernelGGL((k_attention_mfma<1, 64>), grid, dim3(64), 0, s, qkv, out, T, Ta, C, order);
+    if (DP == 128) {
+        if (D == 128) launch_attn_inst<8, 128, true>(grid, s, qkv, out, T, Ta, C, order, D);
+        else launch_attn_inst<8, 128, false>(grid, s, qkv, out, T, Ta, C, order, D);
+    } else if (DP == 96) {
+        if (waves == 8) { if (D == 96) launch_attn_inst<8, 96, true>(grid, s, qkv, out, T, Ta, C, order, D); else launch_attn_inst<8, 96, false>(grid, s, qkv, out, T, Ta, C, order, D); }
+        else { if (D == 96) launch_attn_inst<4, 96, true>(grid, s, qkv, out, T, Ta, C, order, D); else launch_attn_inst<4, 96, false>(grid, s, qkv, out, T, Ta, C, order, D); }
+    } else if (DP == 64) {
+        if (D == 64) {
+            if (waves == 4) launch_attn_inst<4, 64, true>(grid, s, qkv, out, T, Ta, C, order, D);
+            else if (waves == 2) launch_attn_inst<2, 64, true>(grid, s, qkv, out, T, Ta, C, order, D);
+            else launch_attn_inst<1, 64, true>(grid, s, qkv, out, T, Ta, C, order, D);
+        } else {
+            if (waves < 2) { waves = 2; grid = dim3(cdiv(T, 64), heads, N); }
+            if (waves == 4) launch_attn_inst<4, 64, false>(grid, s, qkv, out, T, Ta, C, order, D);
+            else launch_attn_inst<2, 64, false>(grid, s, qkv, out, T, Ta, C, order, D);
+        }
     } else {
-        if (waves == 8) hipLaunchKernelGGL((k_attention_mfma<8, 32>), grid, dim3(512), 0, s, qkv, out, T, Ta, C, order);
-        else if (waves == 4) hipLaunchKernelGGL((k_attention_mfma<4, 32>), grid, dim3(256), 0, s, qkv, out, T, Ta, C, order);
-        else if (waves == 2) hipLaunchKernelGGL((k_attention_mfma<2, 32>), grid, dim3(128), 0, s, qkv, out, T, Ta, C, order);
-        else hipLaunchKernelGGL((k_attention_mfma<1, 32>), grid, dim3(64), 0, s, qkv, out, T, Ta, C, order);
+        if (D == 32) {
+            if (waves == 8) launch_attn_inst<8, 32, true>(grid, s, qkv, out, T, Ta, C, order, D);
+            else if (waves == 4) launch_attn_inst<4, 32, true>(grid, s, qkv, out, T, Ta, C, order, D);
+            else if (waves == 2) launch_attn_inst<2, 32, true>(grid, s, qkv, out, T, Ta, C, order, D);
+            else launch_attn_inst<1, 32, true>(grid, s, qkv, out, T, Ta, C, order, D);
+        } else {
+            if (waves > 4) waves = 4;
+            grid = dim3(cdiv(T, 32 * waves), heads, N);
+            if (waves == 4) launch_attn_inst<4, 32, false>(grid, s, qkv, out, T, Ta, C, order, D);
+            else if (waves == 2) launch_attn_inst<2, 32, false>(grid, s, qkv, out, T, Ta, C, order, D);
+            else launch_attn_inst<1, 32, false>(grid, s, qkv, out, T, Ta, C, order, D);
+        }
     }
     CCDM_CHECK_LAUNCH("attention_mfma");
     return 0;

@@ -139,6 +139,7 @@ __global__ __launch_bounds__(64) void k_attention(const float* __restrict__ qkv,
 }
 
 int launch_attention_mfma(const float* qkv, float* out, int N, int T, int Ta, int C, int heads, int order, hipStream_t s);
+int attention_mfma_width(int D);
 
 int launch_attention(const float* qkv, float* out, int N, int T, int Ta, int C, int heads, int order, hipStream_t s) {
     CCDM_REQUIRE(qkv && out, "attention: null pointer");
@@ -147,14 +148,22 @@ int launch_attention(const float* qkv, float* out, int N, int T, int Ta, int C, 
     const int D = C / heads;
     const bool force_valu = (order & 256) != 0;       // test hook: bit 8 selects the VALU kernel
     order &= 255;
-    // head width 32: the U-Net path (token count a multiple of 32, dense rows); head width 64: the ViT feature encoder (any T, padded rows)
-    if (((D == 32 && T % 32 == 0 && Ta == T) || D == 64) && !force_valu) return launch_attention_mfma(qkv, out, N, T, Ta, C, heads, order, s);
+    // Matrix-core kernel: every head width that is a multiple of 4 up to 128 (padded to 32 / 64 / 96 / 128 inside).  Head width 32 with
+    // a token count that is not a multiple of 32 keeps the VALU kernel it has always run on (round-1 behaviour, bit for bit).
+    const bool mfma_ok = attention_mfma_width(D) > 0 && !(D == 32 && (T % 32 != 0 || Ta != T));
+    if (mfma_ok && !force_valu) return launch_attention_mfma(qkv, out, N, T, Ta, C, heads, order, s);
     dim3 grid(cdiv(T, 64), heads, N), block(64);
-    switch (D) {
+    switch (D) {      // VALU kernel: q and o of one query live in a lane's registers, so the widths are instantiated one by one
+        case 4: hipLaunchKernelGGL(k_attention<4>, grid, block, 0, s, qkv, out, T, Ta, C, heads, order); break;
+        case 8: hipLaunchKernelGGL(k_attention<8>, grid, block, 0, s, qkv, out, T, Ta, C, heads, order); break;
+        case 12: hipLaunchKernelGGL(k_attention<12>, grid, block, 0, s, qkv, out, T, Ta, C, heads, order); break;
         case 16: hipLaunchKernelGGL(k_attention<16>, grid, block, 0, s, qkv, out, T, Ta, C, heads, order); break;
+        case 24: hipLaunchKernelGGL(k_attention<24>, grid, block, 0, s, qkv, out, T, Ta, C, heads, order); break;
         case 32: hipLaunchKernelGGL(k_attention<32>, grid, block, 0, s, qkv, out, T, Ta, C, heads, order); break;
+        case 48: hipLaunchKernelGGL(k_attention<48>, grid, block, 0, s, qkv, out, T, Ta, C, heads, order); break;
         case 64: hipLaunchKernelGGL(k_attention<64>, grid, block, 0, s, qkv, out, T, Ta, C, heads, order); break;
-        default: return fail("attention: head width %d not built (16/32/64)", D);
+        default: return fail("attention: head width %d (C=%d / heads=%d) is built neither on the matrix cores (multiples of 4 up to 128) nor "
+                             "on the vector path (4, 8, 12, 16, 24, 32, 48, 64): choose num_heads / num_head_channels accordingly", D, C, heads);
     }
     CCDM_CHECK_LAUNCH("attention");
     return 0;

@@ -16,6 +16,19 @@ BLOCK_CASES = {
 }
 EMB_DIM = 128
 
+# AttentionBlock at the head widths the reference's factory accepts beyond the shipped num_head_channels: 32 (G16,
+# tools/gen_goldens_heads.py): create_unet_openai's own defaults num_heads=1, num_head_channels=-1 make ONE head as wide as the block
+# (unet_openai/__init__.py:14-15, heads rule unet.py:283-289); num_heads=4 at 96 channels gives width 24.
+HEAD_CASES = {
+    # tag: (channels, num_heads, num_head_channels, new attention order, input shape [N,C,H,W], seed)
+    "attn96_h1": (96, 1, -1, False, (2, 96, 16, 16), 601),        # width 96, T = 256
+    "attn128_h1": (128, 1, -1, False, (2, 128, 8, 8), 602),       # width 128, T = 64
+    "attn96_h4": (96, 4, -1, False, (1, 96, 16, 16), 603),        # width 24
+    "attn128_h1_new": (128, 1, -1, True, (1, 128, 8, 16), 604),   # width 128, new attention order, T = 128
+    "attn64_h1": (64, 1, -1, False, (1, 64, 16, 16), 605),        # width 64 on the U-Net path, T = 256
+    "attn160_h2": (160, 2, -1, False, (1, 160, 8, 8), 606),       # width 80 (padded to 96 inside), T = 64
+}
+
 
 def block_tensors(seed, shapes, x_shape):
     """Deterministic (weights dict, x, emb) for one block.  `shapes` is an ordered {key: shape}."""

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle import ccdm_oracle as O  # noqa: E402
 from ccdm_stochastic_segmentation_amd import hip, build_model, make_unet_spec, make_synthetic_state_dict  # noqa: E402
-from tests.golden_util import BLOCK_CASES, block_tensors  # noqa: E402
+from tests.golden_util import BLOCK_CASES, HEAD_CASES, block_tensors  # noqa: E402
 
 LIDC_BP = dict(base_channels=32, channel_mult=None, attention_resolutions=[32, 16, 8], num_heads=1,
                num_head_channels=32, softmax_output=True)
@@ -383,7 +383,7 @@ def _run_block(U, kind, kw, sd, x, emb, prec):
         qkv, _ = U.conv2d([xs], sd[p + "qkv.weight"].numpy(), sd[p + "qkv.bias"].numpy(), 1, stats=[st],
                           gamma=sd[p + "norm.weight"].numpy(), beta=sd[p + "norm.bias"].numpy(), want_stats=False, prec=prec)
         N, H, W, _ = qkv.shape
-        a = U.attention(qkv.reshape(N, H * W, 3 * C_), C_ // 32, 1 if kw["new"] else 0).reshape(N, H, W, C_)
+        a = U.attention(qkv.reshape(N, H * W, 3 * C_), kw.get("heads", C_ // 32), 1 if kw["new"] else 0).reshape(N, H, W, C_)
         y, _ = U.conv2d([a], sd[p + "proj_out.weight"].numpy(), sd[p + "proj_out.bias"].numpy(), 1, resid=xs, prec=prec)
         return U.bchw(y)
     if kind == "down":
@@ -401,6 +401,64 @@ def test_blocks_vs_reference_golden(U, golden, tag, prec):
     sd = {"b." + k: torch.from_numpy(v) for k, v in w.items()}
     y = _run_block(U, kind, kw, sd, torch.from_numpy(x), torch.from_numpy(emb), prec)
     np.testing.assert_allclose(y.numpy(), golden["g3_blocks"][tag + ".y"], rtol=0, atol=3e-5)
+
+
+@pytest.mark.parametrize("tag", list(HEAD_CASES))
+def test_attention_head_widths_vs_reference_golden(U, golden, tag, parity_log):
+    """G16: AttentionBlock at the head widths the reference's factory accepts beyond 32 — its own defaults num_heads=1,
+    num_head_channels=-1 (width = channels: 96, 128), num_heads=4 at 96 channels (24), width 80 padded to 96 — on the matrix-core
+    attention kernel (any multiple of 4 up to 128), bar 2e-5."""
+    ch, nh, nhc, new, xs, seed = HEAD_CASES[tag]
+    from tests.test_oracle_golden import heads_meta
+    w, x, emb = block_tensors(seed, heads_meta()[tag], xs)
+    sd = {"b." + k: torch.from_numpy(v) for k, v in w.items()}
+    y = _run_block(U, "attn", dict(ch=ch, new=new, heads=nh), sd, torch.from_numpy(x), torch.from_numpy(emb), hip.PREC_F16X3)
+    err = np.abs(y.numpy() - golden["g16_head_widths"][tag + ".y"]).max()
+    parity_log("g16_head_widths", **{tag: err}, bar=2e-5)
+    assert err < 2e-5
+
+
+@pytest.mark.parametrize("D,T,heads,order", [(96, 256, 1, 0), (128, 64, 1, 0), (128, 2048, 2, 1), (24, 256, 4, 0), (80, 100, 2, 0), (48, 96, 3, 1),
+                                              (8, 64, 4, 0), (20, 64, 2, 0), (100, 333, 1, 1), (64, 1024, 1, 0)])
+def test_attention_core_any_head_width(U, D, T, heads, order):
+    """the attention core alone, against the oracle: widths that are multiples of 4 (padded to 32 / 64 / 96 / 128 inside), ragged token
+    counts, both channel orders"""
+    rng = np.random.default_rng(D + T)
+    C = D * heads
+    qkv = rnd(rng, 2, 3 * C, T) * 1.3
+    ref = (O.qkv_attention_new if order else O.qkv_attention_legacy)(qkv, heads)
+    got = U.attention(qkv.permute(0, 2, 1).contiguous().to(U.DEV), heads, order).cpu().permute(0, 2, 1)
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=0, atol=1e-5)
+
+
+def test_attention_refuses_unbuilt_head_width(U):
+    qkv = torch.zeros((1, 64, 3 * 130), device=U.DEV)
+    with pytest.raises(hip.CcdmHipError, match="head width 130"):
+        U.attention(qkv, 1, 0)
+    with pytest.raises(hip.CcdmHipError, match="head width 6"):
+        U.attention(torch.zeros((1, 64, 3 * 6), device=U.DEV), 1, 0)
+
+
+def test_unet_step_default_heads_vs_reference_golden(U, golden, parity_log):
+    """One U-Net step with create_unet_openai's own defaults num_heads=1, num_head_channels=-1 (unet_openai/__init__.py:14-15): attention
+    heads as wide as their blocks (96 channels over 256 tokens, 128 over 64) through build_model and the engine."""
+    g = golden["g16_head_widths"]
+    model = build_model(250, "cosine", {"s": 0.008}, [(1, 128, 128), (2, 128, 128)], (1, 128, 128), "unet_openai",
+                        dict(LIDC_BP, num_heads=1, num_head_channels=-1), "datasets.lidc", "confidence", None)
+    sd = {k: torch.from_numpy(v) for k, v in make_synthetic_state_dict(model.unet.spec, 16).items()}
+    model.unet.load_state_dict(sd, strict=True)
+    model = model.to("cuda:0").eval()
+    rng = np.random.default_rng(1616)
+    image = torch.from_numpy(rng.uniform(-1, 1, (1, 1, 128, 128)).astype(np.float32))
+    idx = torch.from_numpy(rng.integers(0, 2, (1, 128, 128)))
+    out = model(O.one_hot_bchw(idx, 2).to(U.DEV), image.to(U.DEV), t=torch.full((1,), float(g["unet_default_heads.t"])), validation=True)["diffusion_out"]
+    err = np.abs(out.cpu()[:, 0].numpy() - g["unet_default_heads.out_c0"]).max()
+    parity_log("g16_head_widths", unet_default_heads_max_dp=err)
+    assert err < 1e-4
+    # and a short sampling walk runs end to end on it
+    model.philox_advance = False
+    a = model(O.one_hot_bchw(idx, 2).to(U.DEV), image.to(U.DEV), t=torch.as_tensor(10003))["diffusion_out"]
+    assert torch.isfinite(a).all() and (a.sum(1) - 1).abs().max() < 1e-6
 
 
 # ------------------------------------------------------------------------------------------ time tables
