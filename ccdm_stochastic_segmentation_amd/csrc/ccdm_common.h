@@ -94,6 +94,7 @@ static inline void conv_ntiles(int Cout, int* ntiles_padded, int* NI) {
 static inline int conv_cin_pad(int Cin) { return cdiv(Cin, 32) * 32; }
 
 int launch_conv(const ccdm_conv_args& a, hipStream_t s);
+int launch_conv_input_absmax(const ccdm_conv_args& a, float* out, hipStream_t s);
 int launch_attention(const float* qkv, float* out, int N, int T, int Ta, int C, int heads, int order, hipStream_t s);
 int launch_posterior(const ccdm_post_args& a, hipStream_t s);
 int launch_stats_fold(const double* in, int N, int S_in, int C, int S_out, double* out, hipStream_t s);

@@ -234,6 +234,16 @@ extern "C" int ccdm_engine_profile_read(ccdm_engine* e, int op_index, double* me
     return n;
 }
 
+extern "C" int ccdm_engine_input_absmax(ccdm_engine* e, float* out, void* stream) {
+    CCDM_REQUIRE(e && out, "engine_input_absmax: null");
+    for (size_t i = 0; i < e->ops.size(); ++i) {
+        if (e->ops[i].kind != 0) continue;
+        const int rc = launch_conv_input_absmax(e->ops[i].conv, out + i, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 extern "C" int ccdm_engine_describe_op(const ccdm_engine* e, int i, char* buf, int buflen) {
     CCDM_REQUIRE(e && buf && buflen > 0, "engine_describe_op: bad args");
     CCDM_REQUIRE(i >= 0 && i < (int)e->ops.size(), "engine_describe_op: op %d out of range", i);

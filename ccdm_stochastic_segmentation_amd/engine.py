@@ -59,8 +59,12 @@ class SamplerEngine:
 
     def __init__(self, spec: UNetSpec, state_dict: Dict[str, torch.Tensor], N: int, H: int, W: int,
                  num_classes: int, img_channels: int, device: torch.device, max_steps: int,
-                 feature_shape: Optional[Tuple[int, int, int]] = None, prec: int = hip.PREC_F32, fine_slices: int = 0):
+                 feature_shape: Optional[Tuple[int, int, int]] = None, prec: int = hip.PREC_F32, fine_slices: int = 0,
+                 f32_layers=frozenset()):
         self.lib = hip.load()
+        # conv layers (state_dict prefixes, e.g. "input_blocks.3.0.op") pinned to the exact-fp32 kernels inside an F16X3 engine: the
+        # host's per-layer answer to a range overflow (DenoisingModel.on_range_error = "layers")
+        self.f32_layers = frozenset(f32_layers)
         self.fine_slices = int(fine_slices)        # latency slicing level (ccdm_conv_args.fine_slices): more, shorter workgroups per sample
         if device.type != "cuda":
             raise hip.CcdmHipError("SamplerEngine needs a HIP device (torch device 'cuda'); there is no CPU path")
@@ -119,6 +123,7 @@ class SamplerEngine:
               film_off: int = -1, resid: Optional[DevTensor] = None, stats: bool = True,
               skip_src: Optional[Sequence[DevTensor]] = None, skip_key: Optional[str] = None) -> DevTensor:
         sd = self._sd
+        prec = hip.PREC_F32 if wkey in self.f32_layers else self.prec
         a, b = src[0], (src[1] if len(src) > 1 else None)
         cin = a.C + (b.C if b else 0)
         w = sd[wkey + ".weight"].numpy()
@@ -133,12 +138,12 @@ class SamplerEngine:
             # the 1x1 skip connection rides in the same GEMM: shared F16X3 exponents, biases pre-added
             ws = sd[skip_key + ".weight"].numpy().reshape(cout, -1)
             absmax = np.maximum(np.abs(w.reshape(cout, -1)).max(1), np.abs(ws).max(1)).astype(np.float32)
-            skip_w = self._upload(hip.pack_conv_weight(ws.reshape(cout, -1, 1, 1), 1, self.prec, absmax))
+            skip_w = self._upload(hip.pack_conv_weight(ws.reshape(cout, -1, 1, 1), 1, prec, absmax))
             bias_np = bias_np + sd[skip_key + ".bias"].numpy()
         # Upsample + conv 3x3 runs in sub-pixel form (4 taps of the low-resolution input per output pixel instead of 9) where built
         subpixel = bool(up) and ksize == 3 and stride == 1 and resid is None and skip_src is None and not _NO_SUBPIXEL and \
-            bool(self.lib.ccdm_upconv_supported(cin, cout, self.prec))
-        wdev = self._upload(hip.pack_upconv_weight(w, self.prec) if subpixel else hip.pack_conv_weight(w, ksize, self.prec, absmax))
+            bool(self.lib.ccdm_upconv_supported(cin, cout, prec))
+        wdev = self._upload(hip.pack_upconv_weight(w, prec) if subpixel else hip.pack_conv_weight(w, ksize, prec, absmax))
         bias = self._upload(bias_np)
         hin, win = a.h, a.w
         hc, wc = (2 * hin, 2 * win) if up else (hin, win)
@@ -160,7 +165,7 @@ class SamplerEngine:
         args.film, args.film_off = (1, film_off) if film_off >= 0 else (0, 0)
         args.N, args.Hin, args.Win, args.Hout, args.Wout = self.N, hin, win, hout, wout
         args.ksize, args.stride, args.up, args.fine_slices = ksize, stride, up_mode, int(self.fine_slices)
-        args.w, args.bias, args.Cout, args.prec = wdev.data_ptr(), bias.data_ptr(), cout, self.prec
+        args.w, args.bias, args.Cout, args.prec = wdev.data_ptr(), bias.data_ptr(), cout, prec
         args.emb_table, args.emb_stride, args.emb_off = self.emb_table.data_ptr(), self.E, emb_off
         args.emb_row_of_sample = self.rowmap.data_ptr()
         args.step_ptr = 0
@@ -192,7 +197,8 @@ class SamplerEngine:
         self.op_info.append(dict(kind="conv", name=wkey, cin=cin, cout=cout, k=ksize, hin=hin, win=win, hout=hout, wout=wout,
                                  stride=stride, up=bool(up), subpixel=subpixel, gn=gn is not None, skip=skip_src is not None,
                                  # (the launcher's rule for the core-only skip-chunk instantiation k_conv<...,SKWT>: another kernel symbol)
-                                 skip_wide=bool(skip_src is not None and self.prec == hip.PREC_F16X3 and ksize == 3 and stride == 1 and not up
+                                 prec=prec,
+                                 skip_wide=bool(skip_src is not None and prec == hip.PREC_F16X3 and ksize == 3 and stride == 1 and not up
                                                 and wout >= 32 and hout * wout > 512 and cout <= 32
                                                 and all(t.C % 32 == 0 for t in skip_src)),
                                  io_bytes=io, gn_read_bytes=(4 * cin * hin * win if gn is not None else 0), weight_bytes=wbytes, flop=flop))
@@ -216,7 +222,7 @@ class SamplerEngine:
 
     def _attn(self, p: str, l, x: DevTensor) -> DevTensor:
         T_ = x.h * x.w
-        fused = (self.prec == hip.PREC_F16X3 and x.stats is not None and not os.environ.get("CCDM_NO_ATTN_BLOCK")
+        fused = (self.prec == hip.PREC_F16X3 and (p + ".qkv") not in self.f32_layers and x.stats is not None and not os.environ.get("CCDM_NO_ATTN_BLOCK")
                  and self.lib.ccdm_norm_qkv_attention_supported(T_, l.ch, l.heads))
         if fused:
             # GroupNorm + qkv + attention core in one launch (low-resolution stages): the 3C-wide qkv tensor stays on chip
@@ -458,6 +464,18 @@ class SamplerEngine:
         if self.head_ce is None:
             return None
         return self.head_ce.buf[..., : self.K - 1].clone().permute(0, 3, 1, 2)
+
+    def input_absmax(self) -> Dict[str, float]:
+        """F16X3 range diagnostics on the tensors the last run left behind (synchronises): for every conv op its state_dict prefix ->
+        the largest |a| it stages (include/ccdm_hip.h: ccdm_conv_input_absmax; Inf if a value is not finite).  Meaningful on an engine
+        whose values are trustworthy — the exact-fp32 one, or an F16X3 one that did not overflow."""
+        n = self.n_unet_ops
+        buf = torch.zeros((n,), dtype=torch.float32, device=self.device)
+        with torch.cuda.stream(self.stream):
+            hip.check(self.lib.ccdm_engine_input_absmax(self._handle, buf.data_ptr(), self._stream()), "engine_input_absmax")
+        self.stream.synchronize()
+        vals = buf.cpu().tolist()
+        return {self.op_names[i]: float(vals[i]) for i in range(n) if self.op_info[i]["kind"] == "conv"}
 
     def check_and_clear_flag(self) -> bool:
         """Synchronises with the engine's stream; True (and the flag cleared) if any head output of the runs since the last check was

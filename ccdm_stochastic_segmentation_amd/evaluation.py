@@ -132,7 +132,8 @@ def apply_sampler_options(model, params: dict) -> None:
     """Build-owned keys of the params file (absent in the reference's YAML, so an unchanged file runs the defaults):
          rng:  "philox" (default, device RNG) | "torch_cpu" (host generator in the reference's consumption order, parity mode)
          prec: "f16x3" (default) | "f32" (exact-fp32 kernels)
-         philox_seed, use_graph, substreams, on_range_error, slicing: DenoisingModel attributes of the same names."""
+         philox_seed, use_graph, substreams, on_range_error (layers | f32 | raise), f32_layers, slicing: DenoisingModel attributes of the
+         same names."""
     from . import hip
     model.rng = str(params.get("rng", "philox"))
     prec = str(params.get("prec", "f16x3")).lower()
@@ -142,7 +143,8 @@ def apply_sampler_options(model, params: dict) -> None:
     model.philox_seed = int(params.get("philox_seed", 0))
     model.use_graph = bool(params.get("use_graph", True))
     model.substreams = int(params.get("substreams", 0))          # 0 = automatic (DenoisingModel)
-    model.on_range_error = str(params.get("on_range_error", "f32"))
+    model.on_range_error = str(params.get("on_range_error", "layers"))
+    model.f32_layers = set(params.get("f32_layers", []) or [])       # conv layers pinned to fp32 up front (tools/range_report.py --pin)
     model.slicing = str(params.get("slicing", "throughput"))
     model._fine_slices(1)                                         # validates the value
 

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("CCDM_LIB") or os.path.join(_HERE, "libccdm_hip.so")      # CCDM_LIB: A/B two builds on one GPU box
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["ccdm_conv.hip", "ccdm_conv_ks.hip", "ccdm_conv1x1.hip", "ccdm_misc.hip", "ccdm_attention.hip", "ccdm_attn_block.hip", "ccdm_sampler.hip", "ccdm_metrics.hip", "ccdm_engine.hip"]
+SOURCES = ["ccdm_conv.hip", "ccdm_conv_ks.hip", "ccdm_conv1x1.hip", "ccdm_misc.hip", "ccdm_attention.hip", "ccdm_attn_block.hip", "ccdm_sampler.hip", "ccdm_metrics.hip", "ccdm_range.hip", "ccdm_engine.hip"]
 # CCDM_EXPERIMENTS=1 builds add the measured-and-rejected kernels of tools/experiments/ and the environment switches the A/B tools use
 # (exp_env in ccdm_common.h); the shipped library contains neither
 EXPERIMENT_SOURCES = [os.path.join(ROOT, "tools", "experiments", "ccdm_conv_pc.hip")]
@@ -29,8 +29,9 @@ DIAG_GENERAL_KERNEL = 2048 << 8     # CCDM_DIAG_GENERAL_KERNEL: OR into ConvArgs
 PREC_F32, PREC_F16X3 = 0, 1
 STEP_SAMPLE, STEP_LAST_CONFIDENCE, STEP_LAST_MAJORITY, STEP_LAST_KEEP, STEP_SOFTMAX_ONLY = 0, 1, 2, 3, 4
 STATS_MAX_SLICES = 64       # CCDM_STATS_MAX_SLICES: what a GroupNorm consumer reads
+F16X3_LIMIT = 4094.0        # CCDM_F16X3_LIMIT: the fp16 split is exact for staged |a| below this
 STATS_FOLD_SLICES = 16      # CCDM_STATS_FOLD_SLICES: what the engine folds a larger slice count to
-ABI_VERSION = 4          # CCDM_ABI_VERSION of include/ccdm_hip.h
+ABI_VERSION = 5          # CCDM_ABI_VERSION of include/ccdm_hip.h
 
 
 class ConvArgs(C.Structure):
@@ -95,6 +96,8 @@ SIGNATURES = {
     "ccdm_upconv_slices": (C.c_int, [C.c_int, C.c_int]),
     "ccdm_pack_upconv_weight": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ccdm_conv2d": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
+    "ccdm_conv_input_absmax": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p, C.c_void_p]),
+    "ccdm_engine_input_absmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "ccdm_stats_fold": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ccdm_norm_qkv_attention_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "ccdm_norm_qkv_attention": (C.c_int, [C.POINTER(AttnBlockArgs), C.c_void_p]),

@@ -292,10 +292,15 @@ class DenoisingModel(nn.Module):
         # single-stream pass (under concurrency a launch's duration no longer describes the kernel).
         self.substreams = 0
         self.prec = hip.PREC_F16X3
-        # what to do when a PREC_F16X3 run reports a range overflow (hip.CcdmRangeError): "f32" = repeat the call with the
-        # exact-fp32 kernels (same seeds, so the samples are the ones an all-fp32 run would have drawn) and log a warning;
-        # "raise" = propagate the error
-        self.on_range_error = "f32"
+        # what to do when a PREC_F16X3 run reports a range overflow (hip.CcdmRangeError):
+        # "layers" (default) = repeat the call with the exact-fp32 kernels (same seeds, so its samples are the ones an all-fp32 run
+        #   would have drawn), measure on that run what every conv stages (ccdm_engine_input_absmax) and pin the layers whose staged
+        #   values come within RANGE_MARGIN of the fp16 split's limit to the exact-fp32 kernels from then on (`f32_layers`): later
+        #   calls run the F16X3 engine with those few layers in fp32 instead of paying 4x for everything;
+        # "f32" = only repeat the call in fp32 (round-2 behaviour); "raise" = propagate the error
+        self.on_range_error = "layers"
+        self.f32_layers: set = set()
+        self._range_probe: Optional[Dict[str, float]] = None        # filled while a diagnosing fp32 re-run is under way
         # workgroup slicing of the conv kernels: "throughput" (default) = the batch-size-independent rule — samples do not depend on how
         # a batch is sharded over ranks or sub-batches, bit for bit; "latency" = up to 32 one- or two-tile workgroups per sample
         # (ccdm_conv_args.fine_slices) for batches too small to fill the chip (LIDC batch 8: 2.05 -> 1.39 ms per denoise step; batch
@@ -348,13 +353,15 @@ class DenoisingModel(nn.Module):
         if not spec.feature_condition_idx:
             fshape = None                        # no injection point configured: the reference ignores the tensor too
         dev = next(self.unet.parameters()).device
-        key = (N, H, W, int(condition.shape[1]), fshape, str(dev), self.prec, slot, self._fine_slices(N))
+        f32_layers = frozenset(self.f32_layers) if self.prec == hip.PREC_F16X3 else frozenset()
+        key = (N, H, W, int(condition.shape[1]), fshape, str(dev), self.prec, slot, self._fine_slices(N), f32_layers)
         wkey = self._weights_key()
         hit = self._engines.get(key)
         if hit is not None and hit[0] == wkey:
             return hit[1]
         eng = SamplerEngine(spec, self.unet.state_dict(), N, H, W, K, int(condition.shape[1]), dev,
-                            max_steps=self.time_steps, feature_shape=fshape, prec=self.prec, fine_slices=self._fine_slices(N))
+                            max_steps=self.time_steps, feature_shape=fshape, prec=self.prec, fine_slices=self._fine_slices(N),
+                            f32_layers=f32_layers)
         self._engines = {k: v for k, v in self._engines.items() if v[0] == wkey}
         self._engines[key] = (wkey, eng)
         return eng
@@ -372,21 +379,45 @@ class DenoisingModel(nn.Module):
     def _to_index(x: Tensor, device) -> Tensor:
         return x.argmax(dim=1).to(device=device, dtype=torch.uint8).contiguous()
 
+    # staged values within this factor of hip.F16X3_LIMIT pin a layer to fp32 (the probe sees two steps of one call, not every input)
+    RANGE_MARGIN = 0.5
+
+    def _probe_ranges(self, engines) -> None:
+        """diagnosing fp32 re-run: fold what every conv of these (exact-fp32) engines staged in its last step into the probe"""
+        if self._range_probe is None:
+            return
+        for eng in engines:
+            for name, v in eng.input_absmax().items():
+                self._range_probe[name] = max(self._range_probe.get(name, 0.0), v)
+
     def _with_range_fallback(self, fn):
+        if self.on_range_error not in ("layers", "f32", "raise"):
+            raise ValueError(f"on_range_error: {self.on_range_error!r} (expected 'layers', 'f32' or 'raise')")
         state = torch.get_rng_state() if self.rng == "torch_cpu" else None
         try:
             return fn()
         except hip.CcdmRangeError as e:
-            if self.prec == hip.PREC_F32 or self.on_range_error != "f32":
+            if self.prec == hip.PREC_F32 or self.on_range_error == "raise":
                 raise
             LOGGER.warning("%s -- repeating this call with the exact-fp32 kernels", e)
             if state is not None:
                 torch.set_rng_state(state)
             prec, self.prec = self.prec, hip.PREC_F32
+            self._range_probe = {} if self.on_range_error == "layers" else None
             try:
-                return fn()
+                out = fn()
             finally:
                 self.prec = prec
+                probe, self._range_probe = self._range_probe, None
+            if probe:
+                limit = hip.F16X3_LIMIT * self.RANGE_MARGIN
+                hot = sorted(k for k, v in probe.items() if not (v < limit))
+                new = [k for k in hot if k not in self.f32_layers]
+                if new:
+                    self.f32_layers.update(new)
+                    LOGGER.warning("F16X3 range: %d conv layer(s) stage values beyond %.0f (%s ...); they run the exact-fp32 kernels from now on "
+                                   "(DenoisingModel.f32_layers)", len(new), limit, ", ".join(new[:4]))
+            return out
 
     def forward_step(self, x: Tensor, condition: Tensor, feature_condition: Tensor, t: Tensor) -> dict:
         return self._with_range_fallback(lambda: self._forward_step(x, condition, feature_condition, t))
@@ -415,6 +446,7 @@ class DenoisingModel(nn.Module):
             logits = eng.ce_logits()
         eng.leave()
         eng.raise_if_flagged()
+        self._probe_ranges([eng])
         return {"diffusion_out": out, "logits": logits}
 
     def _forward_denoising(self, x: Optional[Tensor], condition: Tensor, feature_condition: Tensor,
@@ -465,6 +497,8 @@ class DenoisingModel(nn.Module):
             blocks = [(s0, min(s0 + blk, S)) for s0 in range(0, S, blk)]
         else:
             blocks = [(0, S)]
+        if self._range_probe is not None and S > 1:      # diagnosing fp32 re-run: look at the first step's activations too
+            blocks = [(0, 1)] + [(max(s0, 1), s1) for s0, s1 in blocks if s1 > 1]
         for s0, s1 in blocks:
             noises: List[Optional[Tensor]] = [None] * nsub
             if host_rng:
@@ -483,6 +517,7 @@ class DenoisingModel(nn.Module):
                     for j, (eng, lo, hi) in enumerate(parts):
                         eng.run(1, first_row=s, noise=noises[j], noise_row0=s0, philox_seed=key,
                                 sample_offset=self.sample_offset + lo, use_graph=self.use_graph)
+            self._probe_ranges([p_[0] for p_ in parts])
         outs = []
         for eng, lo, hi in parts:
             with eng.enter():

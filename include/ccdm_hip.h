@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define CCDM_ABI_VERSION 4
+#define CCDM_ABI_VERSION 5
 #define CCDM_MAX_CHANNELS 1024      /* max C0+C1 of a GroupNorm'ed conv input */
 #define CCDM_STATS_MAX_SLICES 64    /* partial-statistics slices per sample a GroupNorm consumer reads (more: ccdm_stats_fold) */
 #define CCDM_STATS_FOLD_SLICES 16   /* what ccdm_stats_fold reduces a larger slice count to */
@@ -118,6 +118,13 @@ size_t ccdm_pack_upconv_weight(const float* oihw /*[Cout,Cin,3,3]*/, int Cout, i
 /* out[n][j] = sum of in[n][i] over i in [j*S_in/S_out, (j+1)*S_in/S_out), ascending (fixed order); S_out <= CCDM_STATS_MAX_SLICES (the engine folds to CCDM_STATS_FOLD_SLICES) */
 int ccdm_stats_fold(const double* in /*dev [N,S_in,C,2]*/, int N, int S_in, int C, int S_out, double* out /*dev [N,S_out,C,2]*/, void* stream);
 int ccdm_conv2d(const ccdm_conv_args* a, void* stream);
+
+/* F16X3 range diagnostics: max |a| over everything this conv stages — the main input after GroupNorm (+ SiLU) where it normalises on
+ * load, raw otherwise, and the raw input of the fused 1x1 skip segment — before the kernel's 2^4 pre-scale; Inf if any value is not
+ * finite.  The result is max'ed INTO *out (dev float, >= 0: zero it first); the split is exact for values below CCDM_F16X3_LIMIT.
+ * Not on the sampling path: tools/range_report.py and the host's per-layer fp32 fallback call it. */
+#define CCDM_F16X3_LIMIT 4094.0f
+int ccdm_conv_input_absmax(const ccdm_conv_args* a, float* out /*dev [1]*/, void* stream);
 
 /* host-side weight packing.  `oihw` = reference layout [Cout,Cin,k,k] (conv2d) / [Cout,Cin,1] (conv1d).
  * Returns the packed size in bytes (call with out=NULL to query). */
@@ -281,6 +288,9 @@ int ccdm_engine_run(ccdm_engine* e, int first_row, int n_steps, int with_epilogu
  * mean/min/max in ms. */
 int ccdm_engine_profile_op(ccdm_engine* e, int op_index, int capacity);
 int ccdm_engine_profile_read(ccdm_engine* e, int op_index, double* mean_ms, double* min_ms, double* max_ms);
+/* ccdm_conv_input_absmax of every conv op of the step on the tensors the last run left behind: out[i] = max(out[i], ...) for conv op i
+ * (other ops: untouched).  out: dev float [ccdm_engine_num_ops], zeroed by the caller. */
+int ccdm_engine_input_absmax(ccdm_engine* e, float* out, void* stream);
 /* describe op i: writes a short text ("conv3x3 32->32 @128x128 gn silu ...") */
 int ccdm_engine_describe_op(const ccdm_engine* e, int i, char* buf, int buflen);
 

@@ -1387,6 +1387,7 @@ def test_trained_like_weights_overflow_is_loud_and_falls_back(U, parity_log):
         model(x.to(U.DEV), img.to(U.DEV), t=t, validation=True)
     model.on_range_error = "f32"
     got = model(x.to(U.DEV), img.to(U.DEV), t=t, validation=True)["diffusion_out"].cpu()
+    assert not model.f32_layers
     model.prec = hip.PREC_F32
     exact = model(x.to(U.DEV), img.to(U.DEV), t=t, validation=True)["diffusion_out"].cpu()
     assert torch.equal(got, exact)
@@ -1400,6 +1401,69 @@ def test_trained_like_weights_overflow_is_loud_and_falls_back(U, parity_log):
     model.prec = hip.PREC_F32
     b = model(x.to(U.DEV), img.to(U.DEV), t=torch.as_tensor(10003))["diffusion_out"]
     assert torch.isfinite(a).all() and torch.equal(a, b)
+    # ---- on_range_error = "layers" (the default): the offending call is repeated in fp32 (bit-identical to the all-fp32 run) AND the
+    #      layers that stage out-of-range values are pinned to the exact-fp32 kernels; later calls run the F16X3 engine with those few
+    #      layers in fp32, raise nothing and hold the 1e-4 bar ----
+    model.prec, model.on_range_error = hip.PREC_F16X3, "layers"
+    first = model(x.to(U.DEV), img.to(U.DEV), t=t, validation=True)["diffusion_out"].cpu()
+    assert torch.equal(first, exact)
+    pinned = set(model.f32_layers)
+    n_conv = sum(1 for o in model._engine(x.to(U.DEV), img.to(U.DEV), None).op_info if o["kind"] == "conv")
+    parity_log("trained_like_outlier_weights_layer_fallback", layers_pinned=len(pinned), conv_layers=n_conv)
+    assert 0 < len(pinned) < n_conv // 2, sorted(pinned)
+    assert "input_blocks.3.0.op" in pinned                 # Downsample reads the raw residual stream with the +-4094 outlier channel
+    model.on_range_error = "raise"                         # the mixed engine must not overflow any more
+    mixed = model(x.to(U.DEV), img.to(U.DEV), t=t, validation=True)["diffusion_out"].cpu()
+    err_mixed = (mixed - ref).abs().max().item()
+    parity_log("trained_like_outlier_weights_layer_fallback", max_dp=err_mixed, bar=1e-4)
+    assert err_mixed < 1e-4
+    c = model(x.to(U.DEV), img.to(U.DEV), t=torch.as_tensor(10003))["diffusion_out"]
+    assert torch.isfinite(c).all() and ((c - b).abs() > 1e-3).float().mean().item() <= FREE_RUN_FRAC
+    # the library's own range probe agrees with torch on a GroupNorm + SiLU conv input and on a raw one
+    eng = model._engine(x.to(U.DEV), img.to(U.DEV), None)
+    probe = eng.input_absmax()
+    assert set(pinned) <= set(probe) and all(np.isfinite(v) for v in probe.values())
+
+
+def test_conv_input_absmax_matches_torch(U):
+    """ccdm_conv_input_absmax: the largest staged |a| of a conv — after GroupNorm + SiLU of the (concatenated) main input, raw for the
+    fused skip sources — against torch; Inf on a non-finite input."""
+    import ctypes as C_
+    rng = np.random.default_rng(77)
+    N = 2
+    xa, xb = rnd(rng, N, 64, 16, 16) * 40 + 3, rnd(rng, N, 32, 16, 16) * 900
+    gamma, beta = 1 + rnd(rng, 96, scale=0.3), rnd(rng, 96, scale=0.3)
+    sk = rnd(rng, N, 32, 16, 16) * 2500
+    srcs = [U.nhwc(xa), U.nhwc(xb)]
+    stats = [U.gn_stats(s_, 2) for s_ in srcs]
+    lib = hip.load()
+
+    def probe(act, gn, skip):
+        a = hip.ConvArgs()
+        a.in0, a.C0, a.in1, a.C1 = srcs[0].data_ptr(), 64, srcs[1].data_ptr(), 32
+        keep = []
+        if gn:
+            g, b = gamma.to(U.DEV), beta.to(U.DEV)
+            keep += [g, b]
+            a.stats0, a.slices0, a.stats1, a.slices1 = stats[0].data_ptr(), 2, stats[1].data_ptr(), 2
+            a.gamma, a.beta = g.data_ptr(), b.data_ptr()
+        a.eps, a.act, a.emb_off = 1e-5, act, -1
+        a.N, a.Hin, a.Win, a.Hout, a.Wout, a.ksize, a.stride, a.Cout, a.prec = N, 16, 16, 16, 16, 3, 1, 32, hip.PREC_F16X3
+        if skip is not None:
+            a.skip0, a.SC0 = skip.data_ptr(), skip.shape[3]
+        out = torch.zeros(1, device=U.DEV)
+        hip.check(lib.ccdm_conv_input_absmax(C_.byref(a), out.data_ptr(), 0), "conv_input_absmax")
+        U.sync()
+        return out.item()
+
+    x = torch.cat([xa, xb], 1)
+    h = F.silu(F.group_norm(x, 32, gamma, beta, 1e-5))
+    assert abs(probe(hip.ACT_SILU, True, None) - h.abs().max().item()) < 1e-4 * h.abs().max().item()
+    assert abs(probe(hip.ACT_NONE, False, None) - x.abs().max().item()) < 1e-6 * x.abs().max().item()
+    sks = U.nhwc(sk)
+    assert abs(probe(hip.ACT_SILU, True, sks) - max(h.abs().max().item(), sk.abs().max().item())) < 1e-3
+    sks[1, 3, 4, 5] = float("nan")
+    assert probe(hip.ACT_SILU, True, sks) == float("inf")
 
 
 def test_trained_like_weights_in_range_stay_on_the_fast_path(U, parity_log):

@@ -365,7 +365,7 @@ def test_sampler_options_from_params_file():
     m = lidc_model()
     assert m.prec == hip.PREC_F16X3 and m.rng == "philox"            # the defaults ARE the benchmarked configuration
     E.apply_sampler_options(m, {})
-    assert m.prec == hip.PREC_F16X3 and m.rng == "philox" and m.on_range_error == "f32"
+    assert m.prec == hip.PREC_F16X3 and m.rng == "philox" and m.on_range_error == "layers"
     E.apply_sampler_options(m, {"prec": "f32", "rng": "torch_cpu", "philox_seed": 9, "substreams": 2, "slicing": "latency"})
     assert m.prec == hip.PREC_F32 and m.rng == "torch_cpu" and m.philox_seed == 9 and m.substreams == 2 and m.slicing == "latency"
     with pytest.raises(ValueError, match="prec"):
