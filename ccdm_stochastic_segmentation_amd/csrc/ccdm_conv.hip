@@ -37,7 +37,8 @@ namespace ccdm {
 // Ablation / timeline switches (bits 8.. of `prec`, used by tools/bench_conv.py) exist only in a -DCCDM_ABLATION build
 // (CCDM_ABLATION=1 python -c "from ccdm_stochastic_segmentation_amd import hip; hip.build()"): as run-time tests they put
 // a branch around every store and every phase of the production kernel.
-//   1 no MFMA | 2 no commit | 4 no loads | 8 no stores | 16 phase timeline | 256 no barriers (wrong results)
+//   1 no MFMA | 2 no commit | 4 no loads | 8 no stores | 16 phase timeline | 32 no weight-fragment staging (wrong results: what
+//   removing the global -> registers -> LDS round trip of the B chunk could buy) | 256 no barriers (wrong results)
 //   512 / 1024: pad the LDS request so that at most 2 / 1 blocks fit a CU (host side, always available)
 #ifdef CCDM_ABLATION
 #define CCDM_DBG(bit) ((dbg & (bit)) != 0)
@@ -219,7 +220,14 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
     // requested with the next halo) were built, parity-tested and measured neutral to slower in rounds 1-2; they are gone.
     constexpr int DEPTH = 1;
     f32x4 reg[DEPTH][NITEM_R];
-    f32x4 regB[1][NITEM_B > 0 ? NITEM_B : 1];
+#ifndef CCDM_BDMA
+#define CCDM_BDMA 1
+#endif
+    // weight fragments by LDS-DMA instead of through registers — on the narrow-tile variants, where the B chunk (36-74 KB) outweighs the
+    // halo tile: same-box A/B per stage 16x16 423 -> 402 us, 32x32 420 -> 414 us per denoise step; the wide-tile variants LOSE with it
+    // (128x128 1358 -> 1378 us: the request sits behind barrier A instead of in front of it, and their chunk is only 18 KB)
+    constexpr bool BDMA = CCDM_BDMA && PREC != CCDM_PREC_F32 && TW < 32;
+    f32x4 regB[1][(NITEM_B > 0 && !BDMA) ? NITEM_B : 1];
     unsigned valid[DEPTH];         // generic walk: bit i = item i lies inside the image
     unsigned rowmask[DEPTH];       // row-structured: bit i = core row of pass i inside the image (wave-uniform)
     unsigned evalid[DEPTH];        //                 bit j = edge item j inside the image
@@ -367,7 +375,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
         const bool sk = ch >= nchunk_main;
         unsigned t_ = tid;
         asm volatile("" : "+v"(t_));
-        if (PREC != CCDM_PREC_F32) {
+        if (PREC != CCDM_PREC_F32 && !BDMA) {
             // B chunk: [tap][k-step] slabs; skip chunks carry one tap (1x1): only their first KST slabs are meaningful,
             // the passes beyond re-read slab 0 (the load stays unconditional: regB[] stays in registers)
             const char* wq = reinterpret_cast<const char*>(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(T_whi, ch) << 32) |
@@ -384,6 +392,38 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                 ts = ts < nslab ? ts : 0u;
                 const unsigned slab = skwc ? ts * wks : (ts / KST) * wtap + (ts % KST) * wks;
                 regB[0][i] = load16_uniform_base(wq + ((size_t)slab << 4), rem);
+            }
+        }
+    };
+    // ---- issueB_dma (BDMA): the same fragments by LDS-DMA (global_load_lds, 1 KB per wave instruction): the chunk's B image in LDS is
+    //      the packed layout itself — [tap][k-step][n-tile][hi|lo][64 lanes] x 16 B, lane-linear — so a fragment slab needs no
+    //      register, no ds_write and no vector instruction besides its request.  Issued behind barrier A (the previous matrix phase
+    //      has released the buffer), it lands while the block commits the halo tile; the barrier in front of the matrix phase waits
+    //      for it (an LDS-DMA counts on vmcnt).
+    auto issueB_dma = [&](const int ch) {
+        const bool sk = ch >= nchunk_main;
+        const char* wq = reinterpret_cast<const char*>(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(T_whi, ch) << 32) |
+                                                       (unsigned)__builtin_amdgcn_readlane(T_wlo, ch));
+        const unsigned wtap = (unsigned)((sk ? k.cin_pad_skip : k.cin_pad) >> 4) * k.ntiles * 128;
+        const unsigned wks = (unsigned)k.ntiles * 128;
+        const bool skwc = SKW && skw && sk;
+        const unsigned nslab = skwc ? (unsigned)(CKS / 16) : (sk ? KST : NTAP * KST);
+        constexpr int UPS = G / 64;                                   // 1 KB units per slab
+        constexpr int NWV = WAVES * KSP;
+        constexpr int MAXU = (NTAP * KST * UPS + NWV - 1) / NWV;
+        const unsigned nunit = nslab * UPS;
+        const unsigned dst0 = (unsigned)(size_t)(skwc ? halo_b + TH * TW * PIXS : reinterpret_cast<char*>(ldsB));
+        unsigned lane_ = lane;
+        asm volatile("" : "+v"(lane_));
+#pragma unroll
+        for (int i = 0; i < MAXU; ++i) {
+            const unsigned u = (unsigned)wave_all + (unsigned)(i * NWV);        // wave-uniform
+            if (u < nunit) {
+                const unsigned ts = u / UPS, part = u % UPS;
+                const unsigned slab = skwc ? ts * wks : (ts / KST) * wtap + (ts % KST) * wks;
+                const char* src = wq + (((size_t)slab + part * 64) << 4) + (lane_ << 4);
+                __builtin_amdgcn_global_load_lds(reinterpret_cast<const __attribute__((address_space(1))) void*>(reinterpret_cast<unsigned long long>(src)),
+                                                 reinterpret_cast<__attribute__((address_space(3))) void*>(dst0 + u * 1024u), 16, 0, 0);
             }
         }
     };
@@ -485,7 +525,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                 if (item < (unsigned)(HP * QPP)) put(std::true_type{}, reg[d][i], ((valid[d] >> i) & 1u) != 0u, (int)(item / QPP));
             }
         }
-        if (PREC != CCDM_PREC_F32) {
+        if (PREC != CCDM_PREC_F32 && !BDMA && !CCDM_DBG(32)) {
 #pragma unroll
             for (int i = 0; i < NITEM_B; ++i) {
                 const int j = (int)t_ + i * NT;
@@ -517,7 +557,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                 *reinterpret_cast<u32x2*>(dd) = hi;
                 *reinterpret_cast<u32x2*>(dd + 2 * CKS) = lo;
             }
-            reinterpret_cast<f32x4*>(halo_b + TH * TW * PIXS)[t_] = regB[0][0];      // [k-step][hi|lo][64 lanes] x 16 B: NT = 2 * 128 items
+            if (!BDMA) reinterpret_cast<f32x4*>(halo_b + TH * TW * PIXS)[t_] = regB[0][0];      // [k-step][hi|lo][64 lanes] x 16 B: NT = 2 * 128 items
         }
     };
     auto commit = [&](auto D_, const int ch) {
@@ -574,9 +614,16 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                     for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
         }
         CCDM_STAMP(2);
-        if (!CCDM_DBG(4)) issueB(D_, chunk);
+        if (!CCDM_DBG(4) && !CCDM_DBG(32)) issueB(D_, chunk);
         if (!CCDM_DBG(256)) __syncthreads();          // previous MFMA phase has finished reading LDS (and ab[] is visible)
         CCDM_STAMP(3);
+        if constexpr (BDMA) {
+            // (the halo registers were requested an iteration ago; naming them here makes the compiler place its wait for them in
+            //  front of the DMA requests — with a DMA in flight it would otherwise wait for EVERYTHING at the commit's first use)
+#pragma unroll
+            for (int i = 0; i < NITEM_R; ++i) asm volatile("" : "+v"(reg[0][i]));
+            if (!CCDM_DBG(4) && !CCDM_DBG(32)) issueB_dma(chunk);
+        }
         if (!CCDM_DBG(2)) commit(D_, chunk);
         CCDM_STAMP(4);
         if (!CCDM_DBG(256)) __syncthreads();

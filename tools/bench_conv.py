@@ -151,7 +151,7 @@ if __name__ == "__main__":
             if os.environ.get("ABLATE"):
                 # 1: no MFMA, 2: no commit (VALU+LDS writes), 4: no prefetch loads, 8: no stores
                 abl = "  | " + " ".join(f"{nm}={run(prec, sh, dbg=d)[0]*1e3:6.1f}" for nm, d in
-                                        [("-mfma", 1), ("-commit", 2), ("-loads", 4), ("-stores", 8), ("ld+st only", 3), ("st only", 7), ("ld only", 11), ("nothing", 15), ("no-barriers(wrong)", 256), ("2blk/CU", 512), ("1blk/CU", 1024), ("2blk ld+st", 512 | 3), ("1blk ld+st", 1024 | 3)])
+                                        [("-Bstage", 32), ("-mfma", 1), ("-commit", 2), ("-loads", 4), ("-stores", 8), ("ld+st only", 3), ("st only", 7), ("ld only", 11), ("nothing", 15), ("no-barriers(wrong)", 256), ("2blk/CU", 512), ("1blk/CU", 1024), ("2blk ld+st", 512 | 3), ("1blk ld+st", 1024 | 3)])
             print(f"{sh[0]:2d}x {sh[1]+sh[2]:3d}->{sh[3]:3d} @{sh[4]:3d}x{sh[5]:3d} k{sh[6]} s{sh[7]} up{sh[8]} gn{sh[9]}: {ms*1e3:8.1f} us  {tf:7.1f} TF/s  {gbs:7.0f} GB/s(io){abl}")
         print(f"weighted conv total per denoise step: {total:.3f} ms")
         if only is None:

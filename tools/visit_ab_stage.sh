@@ -1,0 +1,17 @@
+# same-box A/B of the per-stage sums (single-stream tapped pass): tools/ab/old.so vs the working-tree library
+set -u
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+for l in old new; do
+  if [ $l = old ]; then export CCDM_LIB=$PWD/tools/ab/old.so; else unset CCDM_LIB; fi
+  python bench.py --steps 1 --warmup 1 --no-cpu-baseline --per-op gpurun_out/per_op_ab_$l.json 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$l', round(d['value'], 2), d['per_stage_us'], 'single', round(d['single_stream']['value'],2))"
+done
+python - <<'PY'
+import json
+a=json.load(open('gpurun_out/per_op_ab_old.json')); b=json.load(open('gpurun_out/per_op_ab_new.json'))
+for x,y in zip(a,b):
+    if abs(x['mean_us']-y['mean_us'])>0.04*x['mean_us']: print(x['op'], x['name'], x['shape'], round(x['mean_us'],1), '->', round(y['mean_us'],1))
+PY
