@@ -2,11 +2,12 @@
 # Copy the judged summaries of one gpu_round.sh / pmc_conv.sh visit (gpurun_out/*_$TAG*) into profiles/ (tracked), named per round.
 set -eu
 TAG=${1:?tag}
-R=${2:-r02}
+R=${2:-r03}
 G=gpurun_out; P=profiles
 cpif() { [ -s "$1" ] && cp "$1" "$2" || true; }
-cpif $G/bench_eager_$TAG.json $P/${R}_bench_f16x3_eager.json
-cpif $G/bench_graph_$TAG.json $P/${R}_bench_f16x3_graph.json
+cpif $G/bench_default_$TAG.json $P/${R}_bench_default.json
+cpif $G/bench_eager1_$TAG.json $P/${R}_bench_eager_single_stream.json
+cpif $G/range_report_c2_$TAG.json $P/${R}_range_report_c2.json
 cpif $G/bench_f32_$TAG.json $P/${R}_bench_f32_eager.json
 cpif $G/bench_c4_$TAG.json $P/${R}_bench_c4.json
 cpif $G/bench_c4b64_$TAG.json $P/${R}_bench_c4b64.json
