@@ -99,16 +99,19 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
     // (thread -> (row in pass, column, channel quad), all item-invariant), the 2*PAD edge columns are one extra item for
     // the first few threads.  Row index and row validity are wave-uniform (scalar ALU), the column part of the address
     // is computed once per tile-chunk, every LDS address is thread-constant + immediate: staging costs no per-item VALU
-    // beyond the arithmetic on the data itself.  (Stride 2 keeps the generic item -> (hy, hx) walk.)
-    constexpr bool ROWS = STRIDE == 1;
+    // beyond the arithmetic on the data itself.  Stride 2 (round 3) walks the same way: the core is the CW = 2 TW columns the tile's
+    // outputs read from halo column PAD on, the single left padding column is the edge item (58.7 -> 5x us at 128x128 -> 64x64 with
+    // the generic item -> (hy, hx) walk before).
+    constexpr bool ROWS = true;
+    constexpr int CW = TW * STRIDE;                               // core columns of the halo (halo x = PAD + core column)
     constexpr int PXW = NT / QPP;                                 // halo pixels per pass
-    static_assert(!ROWS || PXW % TW == 0, "a pass must cover whole core rows");
-    constexpr int RPP = ROWS ? PXW / TW : 1;                      // core rows per pass
+    static_assert(!ROWS || PXW % CW == 0, "a pass must cover whole core rows");
+    constexpr int RPP = ROWS ? PXW / CW : 1;                      // core rows per pass
     constexpr int NCORE = ROWS ? (HHt + RPP - 1) / RPP : 0;
-    constexpr int ECOLS = PAD > 0 ? 2 * PAD : 1;                  // edge columns (1: placeholder when there are none)
-    constexpr int EDGE_ITEMS = ROWS ? HHt * 2 * PAD * QPP : 0;
+    constexpr int ECOLS = HWt - CW > 0 ? HWt - CW : 1;            // edge columns: 2 PAD at stride 1, PAD (left only) at stride 2 (1: placeholder when there are none)
+    constexpr int EDGE_ITEMS = ROWS ? HHt * (HWt - CW) * QPP : 0;
     constexpr int NEDGE = (EDGE_ITEMS + NT - 1) / NT;
-    constexpr bool ROW_UNIFORM = ROWS && (TW * QPP) % 64 == 0;    // a wave never straddles two core rows
+    constexpr bool ROW_UNIFORM = ROWS && (CW * QPP) % 64 == 0;    // a wave never straddles two core rows
     constexpr int NITEM = ROWS ? NCORE + NEDGE : (HP * QPP + NT - 1) / NT;   // staging items per thread
     static_assert(NITEM <= 32, "validity mask is 32 bits");
     // Wide skip chunks (SKW; run-time switch k.skip_wide).  A chunk of the fused 1x1 skip segment feeds the centre tap only: it needs no
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
     // thread -> staging coordinates (row-structured walk): channel quad tq, core column px, row within a pass rip.
     // tq and px are re-derived from an opaque copy of tid inside issue/commit: kept live across the MFMA phase and the
     // epilogue they cost registers the kernel does not have (3 waves per SIMD = 168), re-deriving them is 3 VALU ops.
-    const int rip = ROW_UNIFORM ? __builtin_amdgcn_readfirstlane((tid / QPP) / TW) : (tid / QPP) / TW;
+    const int rip = ROW_UNIFORM ? __builtin_amdgcn_readfirstlane((tid / QPP) / CW) : (tid / QPP) / CW;
     // B staging: slab within a pass (wave-uniform: G >= 128 lanes), item within the slab
     const unsigned tgB = B_MULTI ? (unsigned)__builtin_amdgcn_readfirstlane(tid / G) : 0u;
 
@@ -303,13 +306,13 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
         unsigned t_ = tid;
         asm volatile("" : "+v"(t_));     // recompute the item geometry each call: hoisting it costs more registers than ALU
         if constexpr (ROWS) {
-            const int tq = t_ % QPP, px = (t_ / QPP) % TW;
+            const int tq = t_ % QPP, px = (t_ / QPP) % CW;
             const unsigned c = (unsigned)cb + 4u * (unsigned)tq;
             const unsigned cq = min(c, (unsigned)Cs - 4u);
             const bool cok = c < (unsigned)Cs;
             const unsigned rowb = (unsigned)aWin * (unsigned)Cs * 4u;            // bytes per source row (uniform)
             {
-                const int ix = ox0 + px;                                           // core columns: halo x = px + PAD
+                const int ix = ox0 * STRIDE + px;                                  // core columns: halo x = px + PAD
                 xok[d] = cok & (ix < Wc);
                 const int ixc = min(ix, Wc - 1);
                 const unsigned colb = ((unsigned)(ixc >> ups) * (unsigned)Cs + cq) << 2;
@@ -317,7 +320,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
 #pragma unroll
                 for (int i = 0; i < NCORE; ++i) {
                     const int row = rip + i * RPP;
-                    const int iy = oy0 - PAD + row;
+                    const int iy = oy0 * STRIDE - PAD + row;
                     const bool rok = ((unsigned)iy < (unsigned)Hc) & ((i + 1) * RPP <= HHt || row < HHt);
                     // (skip-segment chunks feed the centre tap only: their halo rows/columns are never read, so those requests
                     //  are pointed at the nearest core row/column — a cache hit instead of 25 % more HBM lines)
@@ -333,8 +336,8 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
             for (int j = 0; j < NEDGE; ++j) {
                 const unsigned e = t_ + j * NT;
                 const unsigned side = (e / QPP) % ECOLS, row = e / (ECOLS * QPP);
-                const int hx = side < (unsigned)PAD ? (int)side : TW + (int)side;
-                const int iy = oy0 - PAD + (int)row, ix = ox0 - PAD + hx;
+                const int hx = side < (unsigned)PAD ? (int)side : CW + (int)side;
+                const int iy = oy0 * STRIDE - PAD + (int)row, ix = ox0 * STRIDE - PAD + hx;
                 const bool ok = cok & (e < (unsigned)EDGE_ITEMS) & ((unsigned)iy < (unsigned)Hc) & ((unsigned)ix < (unsigned)Wc);
                 const int iyc = min(max(iy, ylo), yhi), ixc = min(max(ix, xlo), xhi);
                 const unsigned sy = (unsigned)(iyc >> ups), sx = (unsigned)(ixc >> ups);
@@ -435,7 +438,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
         constexpr bool GN = decltype(GN_)::value, ACT = decltype(ACT_)::value;
         unsigned t_ = tid;
         asm volatile("" : "+v"(t_));
-        const int tq = t_ % QPP, px = (t_ / QPP) % TW;
+        const int tq = t_ % QPP, px = (t_ / QPP) % CW;
         float2 t0 = make_float2(1.f, 0.f), t1 = t0, t2 = t0, t3 = t0;
         if (GN) { const int c = c0 + 4 * tq; t0 = ab[c]; t1 = ab[c + 1]; t2 = ab[c + 2]; t3 = ab[c + 3]; }
         // F16X3: activations are pre-scaled by 2^4 (exact; undone through the weight-scale table) so that the lo half of values
@@ -514,7 +517,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                 const unsigned e = t_ + j * NT;
                 if (e < (unsigned)EDGE_ITEMS) {
                     const unsigned side = (e / QPP) % ECOLS, row = e / (ECOLS * QPP);
-                    const int hx = side < (unsigned)PAD ? (int)side : TW + (int)side;
+                    const int hx = side < (unsigned)PAD ? (int)side : CW + (int)side;
                     put(std::true_type{}, reg[d][NCORE + j], ((evalid[d] >> j) & 1u) != 0u, (int)row * HWt + hx);
                 }
             }
@@ -1195,7 +1198,7 @@ int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
     {   // core halo items need no per-lane padding mask when every tile column and every channel quad exists (see ConvK)
         const int SC = a.SC0 + a.SC1;
         const bool chan_ok = a.C0 % ck == 0 && a.C1 % ck == 0 && (!a.skip0 || (a.SC0 % ck == 0 && a.SC1 % ck == 0 && SC > 0));
-        k.core_unmasked = (a.stride == 1 && (up2 ? a.Win : Wc) % g.TW == 0 && chan_ok) ? 1 : 0;
+        k.core_unmasked = ((up2 ? a.Win : Wc) % (g.TW * a.stride) == 0 && chan_ok) ? 1 : 0;
     }
     CCDM_REQUIRE(a.C1 == 0 || a.C0 % ck == 0, "conv: first source has %d channels; a concatenated input must split at a multiple of the %d-channel chunk", a.C0, ck);
     CCDM_REQUIRE(a.SC1 == 0 || a.SC0 % ck == 0, "conv: first skip source has %d channels; a concatenated input must split at a multiple of the %d-channel chunk", a.SC0, ck);
