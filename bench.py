@@ -183,7 +183,7 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count())     # (ranks may share a GPU under CCDM_DIST_BACKEND=gloo: tests only)
     torch.cuda.set_device(dev)
     cfg = CONFIGS[args.config]
     n = args.batch or cfg["batch"]
@@ -252,7 +252,7 @@ def main():
     dt = time.perf_counter() - t0
     per_rank = None
     if world > 1:
-        mine = torch.tensor([dt, t_gather[0]], device=dev, dtype=torch.float64)
+        mine = torch.tensor([dt, t_gather[0]], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         allr = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank = [{"rank": r, "pass_s": float(v[0]) / max(args.steps, 1), "sampling_s": float(v[0] - v[1]) / max(args.steps, 1),
@@ -287,7 +287,10 @@ def main():
 
     # ---- untimed, rank 0 at N = 1: ONE single-stream eager pass with HIP-event taps on every op (on the engine's stream) -> the dominant
     #      kernel's roofline, the per-stage split, the per-op table; then the single-stream figure of the same product path ----
-    if world == 1 and not args.no_secondary:
+    if rank == 0 and not args.no_secondary:
+        # (N > 1: rank 0 alone, on its own shard, without the gather — the other ranks wait at the final barrier)
+        def one_pass():                                            # noqa: F811
+            return model(x, image, feat, **t_arg)["diffusion_out"]
         model.substreams, model.use_graph = 1, False
         one_pass()                                                 # builds the whole-batch executor
         torch.cuda.synchronize()
