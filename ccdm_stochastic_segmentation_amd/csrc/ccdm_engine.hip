@@ -14,11 +14,12 @@ __global__ void k_step_set(int32_t* p, int32_t v) { *p = v; }
 __global__ void k_step_inc(int32_t* p) { *p += 1; }
 
 struct Op {
-    int kind;   // 0 conv, 1 attention core, 2 statistics fold, 3 GroupNorm + qkv + attention core
+    int kind;   // 0 conv, 1 attention core, 2 statistics fold, 3 GroupNorm + qkv + attention core, 4 resample (updown ResBlocks)
     ccdm_conv_args conv;
     const float* qkv; float* out; int N, T, C, heads, order;
     const double* fin; double* fout; int S_in, S_out;
     ccdm_attn_block_args ab;
+    ccdm_resample_args rs;
 };
 
 static int launch_op(const Op& op, hipStream_t s) {
@@ -26,7 +27,8 @@ static int launch_op(const Op& op, hipStream_t s) {
         case 0: return launch_conv(op.conv, s);
         case 1: return launch_attention(op.qkv, op.out, op.N, op.T, op.T, op.C, op.heads, op.order, s);
         case 2: return launch_stats_fold(op.fin, op.N, op.S_in, op.C, op.S_out, op.fout, s);
-        default: return launch_attn_block(op.ab, s);
+        case 3: return launch_attn_block(op.ab, s);
+        default: return launch_resample(op.rs, s);
     }
 }
 
@@ -129,6 +131,16 @@ extern "C" int ccdm_engine_add_stats_fold(ccdm_engine* e, const double* in, int 
     Op op{};
     op.kind = 2;
     op.fin = in; op.fout = out; op.N = N; op.S_in = S_in; op.C = C; op.S_out = S_out;
+    e->ops.push_back(op);
+    drop_graph(e);
+    return (int)e->ops.size() - 1;
+}
+
+extern "C" int ccdm_engine_add_resample(ccdm_engine* e, const ccdm_resample_args* a) {
+    CCDM_REQUIRE(e && a, "engine_add_resample: null");
+    Op op{};
+    op.kind = 4;
+    op.rs = *a;
     e->ops.push_back(op);
     drop_graph(e);
     return (int)e->ops.size() - 1;
@@ -258,8 +270,11 @@ extern "C" int ccdm_engine_describe_op(const ccdm_engine* e, int i, char* buf, i
         snprintf(buf, buflen, "attention T=%d C=%d heads=%d order=%d", op.T, op.C, op.heads, op.order);
     } else if (op.kind == 2) {
         snprintf(buf, buflen, "stats fold %d -> %d slices, C=%d", op.S_in, op.S_out, op.C);
-    } else {
+    } else if (op.kind == 3) {
         snprintf(buf, buflen, "norm+qkv+attention T=%d C=%d heads=%d", op.ab.T, op.ab.C, op.ab.heads);
+    } else {
+        snprintf(buf, buflen, "resample %s C=%d in%dx%d%s%s%s%s", op.rs.mode == CCDM_RESAMPLE_AVGPOOL2 ? "avgpool2" : "nearest-up2", op.rs.C, op.rs.Hin,
+                 op.rs.Win, op.rs.stats ? " gn" : "", op.rs.act ? " silu" : "", op.rs.out_act ? " ->act" : "", op.rs.out_raw ? " ->raw" : "");
     }
     return 0;
 }

@@ -141,7 +141,8 @@ class SamplerEngine:
             skip_w = self._upload(hip.pack_conv_weight(ws.reshape(cout, -1, 1, 1), 1, prec, absmax))
             bias_np = bias_np + sd[skip_key + ".bias"].numpy()
         # Upsample + conv 3x3 runs in sub-pixel form (4 taps of the low-resolution input per output pixel instead of 9) where built
-        subpixel = bool(up) and ksize == 3 and stride == 1 and resid is None and skip_src is None and not _NO_SUBPIXEL and \
+        subpixel = bool(up) and ksize == 3 and stride == 1 and resid is None and skip_src is None and gn is None and emb_off < 0 and \
+            not _NO_SUBPIXEL and \
             bool(self.lib.ccdm_upconv_supported(cin, cout, prec))
         wdev = self._upload(hip.pack_upconv_weight(w, prec) if subpixel else hip.pack_conv_weight(w, ksize, prec, absmax))
         bias = self._upload(bias_np)
@@ -205,7 +206,51 @@ class SamplerEngine:
         self._fold_stats(out)
         return out
 
+    def _resample(self, x: DevTensor, mode: int, *, gn: Optional[str] = None, act: int = hip.ACT_NONE, want_act: bool, want_raw: bool,
+                  name: str) -> Tuple[Optional[DevTensor], Optional[DevTensor]]:
+        """AvgPool2d(2) / nearest x2 of `x`: (R(act(GroupNorm(x))), R(x)) — the two branches of an updown ResBlock (unet.py:243-248)."""
+        ho, wo = (x.h // 2, x.w // 2) if mode == hip.RESAMPLE_AVGPOOL2 else (2 * x.h, 2 * x.w)
+        oa = self._act(x.C, ho, wo, False) if want_act else None
+        orw = self._act(x.C, ho, wo, False) if want_raw else None
+        a = hip.ResampleArgs()
+        a.in_, a.C = x.ptr, x.C
+        if gn is not None:
+            assert x.stats is not None, f"{name}: input has no statistics"
+            a.stats, a.slices = x.stats_ptr, x.slices
+            a.gamma = self._upload(self._sd[gn + ".weight"].numpy()).data_ptr()
+            a.beta = self._upload(self._sd[gn + ".bias"].numpy()).data_ptr()
+        a.eps, a.act = GN_EPS, act
+        a.N, a.Hin, a.Win, a.mode = self.N, x.h, x.w, mode
+        a.out_act, a.out_raw = (oa.ptr if oa else 0), (orw.ptr if orw else 0)
+        hip.check(self.lib.ccdm_engine_add_resample(self._handle, C.byref(a)), "engine_add_resample " + name)
+        self.op_names.append(name)
+        n_out = int(want_act) + int(want_raw)
+        self.op_info.append(dict(kind="resample", name=name, C=x.C, hin=x.h, win=x.w, hout=ho, wout=wo,
+                                 io_bytes=4 * x.C * (x.h * x.w + n_out * ho * wo), gn_read_bytes=0, weight_bytes=0, flop=0))
+        return oa, orw
+
+    def _res_updown(self, p: str, l, x: DevTensor) -> DevTensor:
+        """ResBlock(down=True / up=True), unet.py:243-248: h = in_conv(R(SiLU(GN(x)))), x = R(x), then as every ResBlock (Cout == Cin, so
+        the skip is the identity).  Down: one elementwise pass leaves both pooled tensors and in_conv reads the activated one as is.  Up:
+        in_conv upsamples on load behind its fused GroupNorm + SiLU (nearest commutes with both), only the raw branch is materialised."""
+        off = self.emb_offsets[p]
+        assert l.cin == l.cout, p
+        emb_off = -1 if l.film else off
+        if l.updown == "down":
+            hp, xr = self._resample(x, hip.RESAMPLE_AVGPOOL2, gn=p + ".in_layers.0", act=hip.ACT_SILU, want_act=True, want_raw=True,
+                                    name=p + ".avgpool2")
+            h = self._conv([hp], p + ".in_layers.2", l.cout, 3, emb_off=emb_off)
+        else:
+            _, xr = self._resample(x, hip.RESAMPLE_NEAREST_UP2, want_act=False, want_raw=True, name=p + ".nearest_up2")
+            h = self._conv([x], p + ".in_layers.2", l.cout, 3, gn=p + ".in_layers.0", act=hip.ACT_SILU, up=True, emb_off=emb_off)
+        return self._conv([h], p + ".out_layers.3", l.cout, 3, gn=p + ".out_layers.0", act=hip.ACT_SILU,
+                          film_off=off if l.film else -1, resid=xr)
+
     def _res(self, p: str, l, src: Sequence[DevTensor]) -> DevTensor:
+        if l.updown:
+            if len(src) != 1:
+                raise NotImplementedError(f"{p}: updown ResBlock on a concatenated input")
+            return self._res_updown(p, l, src[0])
         off = self.emb_offsets[p]
         if l.film:
             h = self._conv(src, p + ".in_layers.2", l.cout, 3, gn=p + ".in_layers.0", act=hip.ACT_SILU)

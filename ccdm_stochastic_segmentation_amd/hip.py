@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("CCDM_LIB") or os.path.join(_HERE, "libccdm_hip.so")      # CCDM_LIB: A/B two builds on one GPU box
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["ccdm_conv.hip", "ccdm_conv_ks.hip", "ccdm_conv1x1.hip", "ccdm_misc.hip", "ccdm_attention.hip", "ccdm_attn_block.hip", "ccdm_sampler.hip", "ccdm_metrics.hip", "ccdm_range.hip", "ccdm_engine.hip"]
+SOURCES = ["ccdm_conv.hip", "ccdm_conv_ks.hip", "ccdm_conv1x1.hip", "ccdm_misc.hip", "ccdm_attention.hip", "ccdm_attn_block.hip", "ccdm_sampler.hip", "ccdm_metrics.hip", "ccdm_range.hip", "ccdm_resample.hip", "ccdm_engine.hip"]
 # CCDM_EXPERIMENTS=1 builds add the measured-and-rejected kernels of tools/experiments/ and the environment switches the A/B tools use
 # (exp_env in ccdm_common.h); the shipped library contains neither
 EXPERIMENT_SOURCES = [os.path.join(ROOT, "tools", "experiments", "ccdm_conv_pc.hip")]
@@ -25,13 +25,14 @@ EXPERIMENT_SOURCES = [os.path.join(ROOT, "tools", "experiments", "ccdm_conv_pc.h
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fPIC", "-shared"]
 
 ACT_NONE, ACT_SILU = 0, 1
+RESAMPLE_AVGPOOL2, RESAMPLE_NEAREST_UP2 = 0, 1      # CCDM_RESAMPLE_*
 DIAG_GENERAL_KERNEL = 2048 << 8     # CCDM_DIAG_GENERAL_KERNEL: OR into ConvArgs.prec to bypass the specialised conv kernels (parity tests)
 PREC_F32, PREC_F16X3 = 0, 1
 STEP_SAMPLE, STEP_LAST_CONFIDENCE, STEP_LAST_MAJORITY, STEP_LAST_KEEP, STEP_SOFTMAX_ONLY = 0, 1, 2, 3, 4
 STATS_MAX_SLICES = 64       # CCDM_STATS_MAX_SLICES: what a GroupNorm consumer reads
 F16X3_LIMIT = 4094.0        # CCDM_F16X3_LIMIT: the fp16 split is exact for staged |a| below this
 STATS_FOLD_SLICES = 16      # CCDM_STATS_FOLD_SLICES: what the engine folds a larger slice count to
-ABI_VERSION = 5          # CCDM_ABI_VERSION of include/ccdm_hip.h
+ABI_VERSION = 6          # CCDM_ABI_VERSION of include/ccdm_hip.h
 
 
 class ConvArgs(C.Structure):
@@ -85,6 +86,16 @@ class AttnBlockArgs(C.Structure):
     ]
 
 
+class ResampleArgs(C.Structure):
+    _fields_ = [
+        ("in_", C.c_void_p), ("C", C.c_int32),
+        ("stats", C.c_void_p), ("slices", C.c_int32),
+        ("gamma", C.c_void_p), ("beta", C.c_void_p), ("eps", C.c_float), ("act", C.c_int32),
+        ("N", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32), ("mode", C.c_int32),
+        ("out_act", C.c_void_p), ("out_raw", C.c_void_p),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/ccdm_hip.h declares
 SIGNATURES = {
     "ccdm_version": (C.c_int, []),
@@ -103,6 +114,8 @@ SIGNATURES = {
     "ccdm_norm_qkv_attention": (C.c_int, [C.POINTER(AttnBlockArgs), C.c_void_p]),
     "ccdm_engine_add_norm_qkv_attention": (C.c_int, [C.c_void_p, C.POINTER(AttnBlockArgs)]),
     "ccdm_engine_add_stats_fold": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "ccdm_engine_add_resample": (C.c_int, [C.c_void_p, C.POINTER(ResampleArgs)]),
+    "ccdm_resample": (C.c_int, [C.POINTER(ResampleArgs), C.c_void_p]),
     "ccdm_pack_conv_weight": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ccdm_pack_conv_weight_ex": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ccdm_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -35,6 +35,7 @@ class ResLayer:             # ResBlock                         unet.py:149-262
     cout: int
     film: bool = False      # use_scale_shift_norm
     kind: str = "res"
+    updown: str = ""        # "down" / "up": ResBlock(down=True / up=True) of a resblock_updown network   unet.py:202-208,243-248
 
     @property
     def has_skip_conv(self) -> bool:
@@ -199,8 +200,6 @@ def make_unet_spec(
     if channel_mult is None:
         channel_mult = default_channel_mult(image_size)
     channel_mult = tuple(channel_mult)
-    if resblock_updown:
-        raise NotImplementedError("resblock_updown=True is not on the hot path (SURVEY §8a A10)")
     if use_fp16:
         raise NotImplementedError("use_fp16 is unused by the reference configs (fp16_util.py)")
     mc = base_channels
@@ -260,7 +259,9 @@ def make_unet_spec(
             cnt += 1
             chans.append(ch)
         if level != len(channel_mult) - 1:
-            spec.input_blocks.append([DownLayer(f"input_blocks.{cnt}.0", ch, ch)])
+            # unet.py:586-600: a ResBlock(down=True) with out_channels == channels (identity skip) stands in for Downsample
+            spec.input_blocks.append([ResLayer(f"input_blocks.{cnt}.0", ch, ch, film=use_scale_shift_norm, updown="down")
+                                      if resblock_updown else DownLayer(f"input_blocks.{cnt}.0", ch, ch)])
             cnt += 1
             chans.append(ch)
             ds *= 2
@@ -286,7 +287,9 @@ def make_unet_spec(
                 layers.append(AttnLayer(f"output_blocks.{ob}.{len(layers)}", ch, heads_for(ch, num_heads_upsample),
                                         new_order=use_new_attention_order))
             if level and i == num_res_blocks:
-                layers.append(UpLayer(f"output_blocks.{ob}.{len(layers)}", ch, ch))
+                name = f"output_blocks.{ob}.{len(layers)}"
+                layers.append(ResLayer(name, ch, ch, film=use_scale_shift_norm, updown="up") if resblock_updown     # unet.py:683-697
+                              else UpLayer(name, ch, ch))
                 ds //= 2
             spec.output_blocks.append(layers)
             ob += 1

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define CCDM_ABI_VERSION 5
+#define CCDM_ABI_VERSION 6
 #define CCDM_MAX_CHANNELS 1024      /* max C0+C1 of a GroupNorm'ed conv input */
 #define CCDM_STATS_MAX_SLICES 64    /* partial-statistics slices per sample a GroupNorm consumer reads (more: ccdm_stats_fold) */
 #define CCDM_STATS_FOLD_SLICES 16   /* what ccdm_stats_fold reduces a larger slice count to */
@@ -118,6 +118,33 @@ size_t ccdm_pack_upconv_weight(const float* oihw /*[Cout,Cin,3,3]*/, int Cout, i
 /* out[n][j] = sum of in[n][i] over i in [j*S_in/S_out, (j+1)*S_in/S_out), ascending (fixed order); S_out <= CCDM_STATS_MAX_SLICES (the engine folds to CCDM_STATS_FOLD_SLICES) */
 int ccdm_stats_fold(const double* in /*dev [N,S_in,C,2]*/, int N, int S_in, int C, int S_out, double* out /*dev [N,S_out,C,2]*/, void* stream);
 int ccdm_conv2d(const ccdm_conv_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * The resamplers of the `resblock_updown=True` topology (ResBlock(up=True / down=True), unet.py:202-219 and :242-250, built from
+ * Downsample(ch, use_conv=False) = AvgPool2d(2), unet.py:137-141, and Upsample(ch, use_conv=False) = nearest x2, unet.py:106-114):
+ *   out_act = R(act(GroupNorm(in)))    — the `h` branch of a down block, between in_layers' SiLU and its conv (NULL: not wanted)
+ *   out_raw = R(in)                    — the `x` branch that becomes the block's residual                     (NULL: not wanted)
+ * R = AvgPool2d(2) ([N,H,W,C] -> [N,H/2,W/2,C], floor; sum order ((x00 + x01) + x10) + x11 like torch's CPU kernel, so out_raw is
+ * bit-exact) or nearest x2 ([N,H,W,C] -> [N,2H,2W,C]).  GroupNorm as in ccdm_conv_args: `stats` are the producer's partial-statistics
+ * slices of `in` (NULL: no normalisation; then gamma/beta are unused); C % 4 == 0, with GroupNorm C % 32 == 0.
+ * ------------------------------------------------------------------------------------------------- */
+#define CCDM_RESAMPLE_AVGPOOL2 0
+#define CCDM_RESAMPLE_NEAREST_UP2 1
+typedef struct ccdm_resample_args {
+    const float* in;            /* dev NHWC fp32 [N,Hin,Win,C] */
+    int32_t C;
+    const double* stats;        /* dev [N,slices,C,2] or NULL */
+    int32_t slices;
+    const float* gamma;         /* dev [C] */
+    const float* beta;          /* dev [C] */
+    float eps;
+    int32_t act;                /* CCDM_ACT_NONE / CCDM_ACT_SILU, applied to out_act only */
+    int32_t N, Hin, Win;
+    int32_t mode;               /* CCDM_RESAMPLE_* */
+    float* out_act;
+    float* out_raw;
+} ccdm_resample_args;
+int ccdm_resample(const ccdm_resample_args* a, void* stream);
 
 /* F16X3 range diagnostics: max |a| over everything this conv stages — the main input after GroupNorm (+ SiLU) where it normalises on
  * load, raw otherwise, and the raw input of the fused 1x1 skip segment — before the kernel's 2^4 pre-scale; Inf if any value is not
@@ -274,6 +301,7 @@ int ccdm_engine_add_conv(ccdm_engine* e, const ccdm_conv_args* a);          /* s
 int ccdm_engine_add_attention(ccdm_engine* e, const float* qkv, float* out, int N, int T, int C, int heads, int order);
 int ccdm_engine_add_norm_qkv_attention(ccdm_engine* e, const ccdm_attn_block_args* a);
 int ccdm_engine_add_stats_fold(ccdm_engine* e, const double* in, int N, int S_in, int C, int S_out, double* out);
+int ccdm_engine_add_resample(ccdm_engine* e, const ccdm_resample_args* a);
 int ccdm_engine_set_epilogue(ccdm_engine* e, const ccdm_post_args* a);      /* run after the ops of each step */
 int ccdm_engine_num_ops(const ccdm_engine* e);
 /* per-run mutable fields of the epilogue (everything else is fixed at build time) */

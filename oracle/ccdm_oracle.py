@@ -106,10 +106,20 @@ def group_norm32(x: Tensor, w: Tensor, b: Tensor) -> Tensor:
     return F.group_norm(x.float(), 32, w, b, 1e-5).type(x.dtype)
 
 
-def res_block(sd: Dict[str, Tensor], p: str, x: Tensor, emb: Tensor) -> Tensor:
-    """ResBlock._forward, non-updown variants.   unet.py:242-262."""
-    h = F.conv2d(F.silu(group_norm32(x, sd[p + "in_layers.0.weight"], sd[p + "in_layers.0.bias"])),
-                 sd[p + "in_layers.2.weight"], sd[p + "in_layers.2.bias"], padding=1)
+def res_block(sd: Dict[str, Tensor], p: str, x: Tensor, emb: Tensor, updown: Optional[str] = None) -> Tensor:
+    """ResBlock._forward.   unet.py:242-262.
+
+    updown = "down" / "up": the `resblock_updown=True` variants (:202-208, :243-248) — GroupNorm and SiLU at the input resolution, then
+    h and x both through AvgPool2d(2) (Downsample(ch, False), :137-141) or a nearest x2 upsample (Upsample(ch, False), :106-114),
+    then in_conv."""
+    h = F.silu(group_norm32(x, sd[p + "in_layers.0.weight"], sd[p + "in_layers.0.bias"]))
+    if updown == "down":
+        h, x = F.avg_pool2d(h, 2, 2), F.avg_pool2d(x, 2, 2)
+    elif updown == "up":
+        h, x = F.interpolate(h, scale_factor=2, mode="nearest"), F.interpolate(x, scale_factor=2, mode="nearest")
+    else:
+        assert updown is None, updown
+    h = F.conv2d(h, sd[p + "in_layers.2.weight"], sd[p + "in_layers.2.bias"], padding=1)
     cout = sd[p + "in_layers.2.weight"].shape[0]
     emb_out = F.linear(F.silu(emb), sd[p + "emb_layers.1.weight"], sd[p + "emb_layers.1.bias"])[..., None, None]
     if emb_out.shape[1] == 2 * cout:                                   # use_scale_shift_norm (FiLM) :254-258
@@ -177,13 +187,28 @@ def _heads(ch: int, num_heads: int, num_head_channels: int) -> int:
     return num_heads if num_head_channels == -1 else ch // num_head_channels      # unet.py:283-289
 
 
+def _updown_of(cfg: dict, prefix: str, j: int) -> Optional[str]:
+    """Which ResBlocks of a `resblock_updown=True` network resample (they hold no parameter that says so): the single ResBlock of
+    every encoder block that closes a level (unet.py:586-600: after each `num_res_blocks` blocks, where Downsample would sit) and any
+    ResBlock that is not the first layer of its decoder block (:683-697, where Upsample would sit)."""
+    if not cfg.get("resblock_updown", False):
+        return None
+    stem, idx = prefix.rsplit(".", 1) if prefix[-1].isdigit() else (prefix, "")
+    if stem == "input_blocks":
+        i = int(idx)
+        return "down" if i > 0 and i % (int(cfg["num_res_blocks"]) + 1) == 0 else None
+    if stem == "output_blocks":
+        return "up" if j > 0 else None
+    return None
+
+
 def _run_sequential(sd, prefix: str, h: Tensor, emb: Tensor, cfg: dict, decoder: bool = False) -> Tensor:
     """TimestepEmbedSequential.forward, dispatching on which parameters exist.   unet.py:70-84."""
     j = 0
     while True:
         p = f"{prefix}.{j}."
         if (p + "in_layers.0.weight") in sd:
-            h = res_block(sd, p, h, emb)
+            h = res_block(sd, p, h, emb, _updown_of(cfg, prefix, j))
         elif (p + "qkv.weight") in sd:
             nh = cfg.get("num_heads_upsample", cfg["num_heads"]) if decoder else cfg["num_heads"]
             h = attention_block(sd, p, h, _heads(h.shape[1], nh, cfg["num_head_channels"]),
@@ -211,7 +236,7 @@ def unet_forward(sd: Dict[str, Tensor], cfg: dict, x: Tensor, input_condition: T
     """UNetModel.forward.   unet.py:744-808.
 
     cfg keys: num_heads, num_head_channels, [num_heads_upsample], [use_new_attention_order],
-              [softmax_output=True], [feature_condition_idx=[]].
+              [softmax_output=True], [feature_condition_idx=[]], [resblock_updown=False -> needs num_res_blocks].
     """
     emb = time_embed(sd, timesteps)                                                # :758
     h = torch.cat([x, input_condition], dim=1).float()                             # :760,:767

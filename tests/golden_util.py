@@ -29,6 +29,19 @@ HEAD_CASES = {
     "attn160_h2": (160, 2, -1, False, (1, 160, 8, 8), 606),       # width 80 (padded to 96 inside), T = 64
 }
 
+# ResBlock(down=True / up=True) of the `resblock_updown=True` topology (G17, tools/gen_goldens_updown.py; unet.py:202-208,243-248)
+UPDOWN_CASES = {
+    # tag: (channels, "down" / "up", use_scale_shift_norm, input shape [N,C,H,W], seed)
+    "down64": (64, "down", False, (2, 64, 16, 16), 701),
+    "down32_ragged": (32, "down", False, (2, 32, 20, 12), 702),      # 10x6 output: ragged 8x8 tiles
+    "down96_film": (96, "down", True, (1, 96, 16, 16), 703),
+    "up64": (64, "up", False, (2, 64, 8, 8), 704),
+    "up32_ragged": (32, "up", False, (2, 32, 10, 6), 705),
+    "up96_film": (96, "up", True, (1, 96, 8, 8), 706),
+}
+UPDOWN_BP = dict(base_channels=32, channel_mult=None, attention_resolutions=[32, 16, 8], num_heads=1, num_head_channels=32,
+                 softmax_output=True, resblock_updown=True)
+
 
 def block_tensors(seed, shapes, x_shape):
     """Deterministic (weights dict, x, emb) for one block.  `shapes` is an ordered {key: shape}."""

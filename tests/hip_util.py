@@ -115,6 +115,30 @@ def conv2d(srcs, weight, bias, ksize, *, stats=None, gamma=None, beta=None, act=
     return out, ost
 
 
+def resample(x_nhwc, mode, *, stats=None, gamma=None, beta=None, act=hip.ACT_NONE, want_act=True, want_raw=True):
+    """ccdm_resample: returns (R(act(GN(x))) or None, R(x) or None), NHWC cuda."""
+    lib = hip.load()
+    N, H, W, C_ = x_nhwc.shape
+    ho, wo = (H // 2, W // 2) if mode == hip.RESAMPLE_AVGPOOL2 else (2 * H, 2 * W)
+    # (an empty output — AvgPool2d(2) of a 1-pixel-high image — still gets a real pointer: the library refuses it by geometry)
+    oa = torch.full((N, max(ho, 1), max(wo, 1), C_), float("nan"), device=DEV) if want_act else None
+    orw = torch.full((N, max(ho, 1), max(wo, 1), C_), float("nan"), device=DEV) if want_raw else None
+    a = hip.ResampleArgs()
+    a.in_, a.C = x_nhwc.data_ptr(), C_
+    keep = []
+    if stats is not None:
+        g = torch.as_tensor(np.asarray(gamma, dtype=np.float32)).to(DEV)
+        bt = torch.as_tensor(np.asarray(beta, dtype=np.float32)).to(DEV)
+        keep += [g, bt]
+        a.stats, a.slices, a.gamma, a.beta = stats.data_ptr(), stats.shape[1], g.data_ptr(), bt.data_ptr()
+    a.eps, a.act = 1e-5, act
+    a.N, a.Hin, a.Win, a.mode = N, H, W, mode
+    a.out_act, a.out_raw = (oa.data_ptr() if want_act else 0), (orw.data_ptr() if want_raw else 0)
+    hip.check(lib.ccdm_resample(C.byref(a), 0), "resample")
+    sync()
+    return oa, orw
+
+
 def attention(qkv_ntc: torch.Tensor, heads: int, order: int) -> torch.Tensor:
     lib = hip.load()
     N, T, C3 = qkv_ntc.shape

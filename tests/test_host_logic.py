@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(hip.SIGNATURES), declared ^ set(hip.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ccdm_version() == hip.ABI_VERSION == 5
+    assert lib.ccdm_version() == hip.ABI_VERSION == 6
     assert ctypes.sizeof(hip.ConvArgs) % 8 == 0 and ctypes.sizeof(hip.PostArgs) % 8 == 0
 
 
@@ -53,17 +53,20 @@ def test_struct_layout_matches_header():
       printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(ccdm_post_args), offsetof(ccdm_post_args, step_table), offsetof(ccdm_post_args, philox_seed),
              offsetof(ccdm_post_args, xin_stride), offsetof(ccdm_post_args, posterior_out), offsetof(ccdm_post_args, noise_row0),
              offsetof(ccdm_post_args, range_flag));
+      printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(ccdm_resample_args), offsetof(ccdm_resample_args, stats), offsetof(ccdm_resample_args, gamma),
+             offsetof(ccdm_resample_args, eps), offsetof(ccdm_resample_args, N), offsetof(ccdm_resample_args, mode), offsetof(ccdm_resample_args, out_raw));
       return 0; }'''
     import tempfile
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "t.c"), "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
         out = subprocess.check_output([os.path.join(d, "t")]).decode().split()
-    A, B = hip.ConvArgs, hip.PostArgs
+    A, B, R = hip.ConvArgs, hip.PostArgs, hip.ResampleArgs
     mine = [ctypes.sizeof(A), A.gamma.offset, A.w.offset, A.emb_row_of_sample.offset, A.out.offset, A.out_slices.offset,
             A.SC1.offset, A.skip_w.offset,
             ctypes.sizeof(B), B.step_table.offset, B.philox_seed.offset, B.xin_stride.offset, B.posterior_out.offset,
-            B.noise_row0.offset, B.range_flag.offset]
+            B.noise_row0.offset, B.range_flag.offset,
+            ctypes.sizeof(R), R.stats.offset, R.gamma.offset, R.eps.offset, R.N.offset, R.mode.offset, R.out_raw.offset]
     assert [int(v) for v in out] == mine
 
 

@@ -6,7 +6,7 @@ import torch
 
 from oracle import ccdm_oracle as O
 from ccdm_stochastic_segmentation_amd.unet_spec import make_unet_spec, make_synthetic_state_dict
-from tests.golden_util import BLOCK_CASES, HEAD_CASES, block_tensors
+from tests.golden_util import BLOCK_CASES, HEAD_CASES, UPDOWN_BP, UPDOWN_CASES, block_tensors
 
 LIDC_BP = dict(base_channels=32, channel_mult=None, attention_resolutions=[32, 16, 8], num_heads=1,
                num_head_channels=32, softmax_output=True)
@@ -253,6 +253,72 @@ def test_g16_unet_step_default_heads(golden):
     idx = torch.from_numpy(rng.integers(0, 2, (1, 128, 128)))
     out = O.unet_forward(sd, dict(num_heads=1, num_head_channels=-1), O.one_hot_bchw(idx, 2), image, None, torch.full((1,), float(g["unet_default_heads.t"])))
     np.testing.assert_allclose(out["diffusion_out"][:, 0].numpy(), g["unet_default_heads.out_c0"], rtol=0, atol=1e-6)
+
+
+def updown_meta():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "meta_updown.json")) as f:
+        return json.load(f)
+
+
+UPDOWN_CFG = dict(num_heads=1, num_head_channels=32, resblock_updown=True, num_res_blocks=2)
+
+
+@pytest.mark.parametrize("tag", list(UPDOWN_CASES))
+def test_g17_resblock_updown_blocks(golden, tag):
+    """ResBlock(down=True) / ResBlock(up=True): AvgPool2d(2) / nearest x2 between in_layers' SiLU and its conv, and on the skip path."""
+    ch, mode, film, xs, seed = UPDOWN_CASES[tag]
+    w, x, emb = block_tensors(seed, updown_meta()["block_shapes"][tag], xs)
+    sd = {"b." + k: torch.from_numpy(v) for k, v in w.items()}
+    y = O.res_block(sd, "b.", torch.from_numpy(x), torch.from_numpy(emb), updown=mode)
+    ref = golden["g17_resblock_updown"][tag + ".y"]
+    want = (xs[0], ch, xs[2] // 2, xs[3] // 2) if mode == "down" else (xs[0], ch, 2 * xs[2], 2 * xs[3])
+    assert tuple(y.shape) == ref.shape == want
+    np.testing.assert_allclose(y.numpy(), ref, rtol=0, atol=2e-6)
+
+
+def test_g17_updown_key_layout_and_unet_step(golden):
+    """make_unet_spec(resblock_updown=True) reproduces the reference's state_dict (keys, shapes, order, parameter count); one step of
+    that network through the oracle equals the reference's."""
+    g, meta = golden["g17_resblock_updown"], updown_meta()
+    spec = make_unet_spec(image_size=128, in_channels=3, out_channels=2, **UPDOWN_BP)
+    assert [[k, list(v)] for k, v in spec.param_shapes().items()] == meta["unet_keys"]
+    assert spec.num_params() == meta["unet_params"]
+    assert [l.updown for _, l in spec.all_layers() if l.kind == "res" and l.updown] == ["down"] * 4 + ["up"] * 4
+    assert not any(l.kind in ("down", "up") for _, l in spec.all_layers())
+    sd = {k: torch.from_numpy(v) for k, v in make_synthetic_state_dict(spec, 17).items()}
+    rng = np.random.default_rng(1717)
+    image = torch.from_numpy(rng.uniform(-1, 1, (1, 1, 128, 128)).astype(np.float32))
+    idx = torch.from_numpy(rng.integers(0, 2, (1, 128, 128)))
+    taps = {}
+    out = O.unet_forward(sd, UPDOWN_CFG, O.one_hot_bchw(idx, 2), image, None, torch.full((1,), float(g["unet.t"])), taps=taps)
+    for k in ("input_blocks.3", "output_blocks.2"):
+        assert tuple(taps[k].shape) == tuple(g[f"unet.tap.{k}.shape"])
+        np.testing.assert_allclose(taps[k].mean((2, 3)).numpy(), g[f"unet.tap.{k}.mean_hw"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(out["diffusion_out"][:, 0].numpy(), g["unet.out_c0"], rtol=0, atol=1e-6)
+
+
+def test_g17_updown_walk(golden):
+    """6 strided steps, seed 42, through the resblock_updown network: the free-running oracle reproduces the reference's x_t bitmaps."""
+    g = golden["g17_resblock_updown"]
+    spec = make_unet_spec(image_size=128, in_channels=3, out_channels=2, **UPDOWN_BP)
+    sd = {k: torch.from_numpy(v) for k, v in make_synthetic_state_dict(spec, 17).items()}
+    sched = O.make_schedule("cosine", 250, {"s": 0.008})
+    image = torch.from_numpy(np.random.default_rng(1717).uniform(-1, 1, (1, 1, 128, 128)).astype(np.float32))
+    torch.manual_seed(42)
+    idx, _ = O.draw_x_T(1, 2, 128, 128)
+    assert np.array_equal(idx.numpy(), unpack(g["walk.xT"], (1, 128, 128)))
+    trace = []
+    out = O.forward_denoising(sd, UPDOWN_CFG, sched, O.one_hot_bchw(idx, 2), image, None, 10006, "confidence", trace=trace)["diffusion_out"]
+    assert [r["t"] for r in trace] == list(g["walk.t_values"])
+    xt = idx
+    for j, r in enumerate(trace):
+        assert np.array_equal(xt.numpy(), unpack(g[f"walk.xt_{j}"], (1, 128, 128))), f"x_t differs at step {j}"
+        np.testing.assert_allclose(r["x0pred"][:, 0, ::16, ::16].numpy(), g[f"walk.x0pred0_{j}"], atol=2e-6)
+        if "idx" in r:
+            xt = r["idx"]
+    np.testing.assert_allclose(out[:, 0].numpy(), g["walk.out_c0"], atol=2e-6)
 
 
 def test_g9_caller_reenactment(golden):
