@@ -263,7 +263,11 @@ int launch_attention_mfma(const float* qkv, float* out, int N, int T, int Ta, in
     // (T = 8192, N = 4, 4 heads: 570 -> 502 us = 29.0 -> 32.8 % of the fp16 matrix peak by instruction count; T = 2048: 90 -> 83 us)
     const int w8_env = exp_env("CCDM_ATTN_W8_MIN");      // A/B hook of CCDM_EXPERIMENTS builds (-1: never)
     const int w8_min = w8_env ? w8_env : 2048;
-    int waves = (DP == 32 && w8_min > 0 && T >= w8_min) ? 8 : (T >= 128 ? 4 : (T >= 64 ? 2 : 1));
+    // ... as long as the 8-wave grid still covers the chip: at T = 2048 with 4 samples x 4 heads it is 128 blocks on 256 CUs, and 256
+    // 4-wave blocks run the same launch in 52 instead of 63 us.  (Every wave owns its queries and walks the same key tiles in the same
+    // order: the block shape changes no result bit, so the rule may look at N.)
+    const bool w8 = DP == 32 && w8_min > 0 && T >= w8_min && (long long)cdiv(T, 256) * heads * N >= 256;
+    int waves = w8 ? 8 : (T >= 128 ? 4 : (T >= 64 ? 2 : 1));
     // wide heads: the staged K/V items and the query fragments of a wave grow with the width — keep them inside the register file by
     // spreading a key tile over more threads (96: at least 4 waves; 128: always 8)
     if (DP == 96 && waves < 4) waves = 4;

@@ -18,7 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ["ccdm_conv.hip", "ccdm_conv_ks.hip", "ccdm_conv1x1.hip", "ccdm_misc.hip", "ccdm_attention.hip", "ccdm_attn_block.hip", "ccdm_sampler.hip", "ccdm_metrics.hip", "ccdm_range.hip", "ccdm_resample.hip", "ccdm_engine.hip"]
 # CCDM_EXPERIMENTS=1 builds add the measured-and-rejected kernels of tools/experiments/ and the environment switches the A/B tools use
 # (exp_env in ccdm_common.h); the shipped library contains neither
-EXPERIMENT_SOURCES = [os.path.join(ROOT, "tools", "experiments", "ccdm_conv_pc.hip")]
+EXPERIMENT_SOURCES = [os.path.join(ROOT, "tools", "experiments", "ccdm_conv_pc.hip"), os.path.join(ROOT, "tools", "experiments", "ccdm_attention_split.hip")]
 # -amdgpu-mfma-vgpr-form: MFMA accumulators stay in the (unified) VGPR file.  The default heuristic parks them in AccVGPRs and pays a
 # v_accvgpr_read/_write for every vector op that touches a score or an output accumulator: 240 extra instructions per key tile in
 # the attention kernels (2066 in ccdm_attention.hip, 576 in ccdm_attn_block.hip; the conv kernels have none either way).

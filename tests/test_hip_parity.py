@@ -431,6 +431,17 @@ def test_attention_core_any_head_width(U, D, T, heads, order):
     np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=0, atol=1e-5)
 
 
+def test_attention_block_shape_rule_is_bit_neutral(U):
+    """The long-sequence kernel runs 8-wave blocks only while that grid still covers the chip (ccdm_attention.hip: T >= 2048 and
+    >= 256 blocks), 4-wave blocks otherwise — a rule that looks at the batch size.  Every wave owns its queries and walks the same key
+    tiles in the same order, so a sample's output must not depend on how many samples share the launch."""
+    g = torch.Generator(device="cpu").manual_seed(2048)
+    qkv = (torch.randn((20, 2048, 3 * 128), generator=g) * 1.2).to(U.DEV)
+    big = U.attention(qkv, 4, 0)                  # 8 x 4 x 20 = 640 blocks of 8 waves
+    small = U.attention(qkv[:3].contiguous(), 4, 0)      # 8 x 4 x 3 = 96 < 256: 4-wave blocks
+    assert torch.equal(big[:3], small)
+
+
 def test_attention_refuses_unbuilt_head_width(U):
     qkv = torch.zeros((1, 64, 3 * 130), device=U.DEV)
     with pytest.raises(hip.CcdmHipError, match="head width 130"):
