@@ -366,13 +366,13 @@ def main():
         for i, o in enumerate(info):
             cnt, m, lo, hi = taps[i]
             per_op.append(dict(op=i, name=o["name"], kind=o["kind"], mean_us=m * 1e3, min_us=lo * 1e3, max_us=hi * 1e3,
-                               shape=(f"{o['cin']}->{o['cout']} k{o['k']} @{o['hout']}x{o['wout']}" if o["kind"] == "conv" else
+                               shape=(f"{o['cin']}->{o['cout']} k{o['k']} @{o['hout']}x{o['wout']}" if o["kind"] in ("conv", "conv_head") else
                                       (f"T={o['T']} C={o['C']}" if "T" in o else "")),
                                hbm_frac=(o["io_bytes"] * n + o["gn_read_bytes"] * n + o["weight_bytes"]) / max(m, 1e-9) / 1e6 / HBM_PEAK_GBS))
         by_stage = {}
         for p in per_op:
             o = info[p["op"]]
-            key = f"{o['hout']}x{o['wout']}" if o["kind"] == "conv" else o["kind"]
+            key = f"{o['hout']}x{o['wout']}" if o["kind"] in ("conv", "conv_head", "resample") else o["kind"]
             by_stage[key] = by_stage.get(key, 0.0) + p["mean_us"]
         res["per_stage_us"] = {k_: round(v, 1) for k_, v in by_stage.items()}
         res["per_stage_note"] = "sum of per-op mean launch times of the tapped single-stream pass, grouped by output size"
