@@ -168,6 +168,8 @@ def test_state_dict_layout_and_strict_load(golden):
 
 
 def test_builder_contract():
+    with pytest.raises(ValueError, match="40 classes"):
+        P.build_model(250, "cosine", None, [(3, 64, 64), (40, 64, 64)], (3, 64, 64), "unet_openai", dict(base_channels=32), "datasets.lidc", "confidence", None)
     with pytest.raises(NotImplementedError, match="backbone resnet50"):
         P.build_model(250, "cosine", None, [(1, 128, 128), (2, 128, 128)], None, "resnet50", {}, "x")
     with pytest.raises(ValueError, match="unsupported image size"):
