@@ -29,6 +29,7 @@ DINO_FCE = dict(type="dino", model="dino_vits8", channels=384, conditioning="con
                 scale="single", train=False, source_layer=11, target_layer=10)
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s is what a streaming copy reaches)
 MFMA_PEAK_TFLOPS = 2500.0        # dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
+MFMA_MEASURED_TFLOPS = 1730.0    # what back-to-back v_mfma_f32_32x32x16_f16 sustain with random-mantissa operands (tools/ubench/mfma_chain.hip: 38.7 vs 27.1 "cycles")
 # measured in the build container (tools/time_reference_cpu.py -> profiles/r03_reference_vs_oracle_cpu.json: 8 interleaved runs each,
 # median of the per-pair ratios, range 0.87-1.07): the oracle takes 0.96x the REAL reference's time per denoise step on the same
 # inputs, outputs bit-identical — inside the +-10 % BASELINE.md §3 asks for.  (Round 1's 1.148 came from one sequential pair of runs.)
@@ -345,7 +346,9 @@ def main():
                 # matrix-pipe utilisation from the instruction count: every fp32 product is 3 fp16 MFMA products (hi*hi, hi*lo, lo*hi);
                 # relative to the dense fp16 peak at the top clock (the PMC figure SQ_VALU_MFMA_BUSY_CYCLES is in profiles/)
                 "mfma_util": (3.0 if f16 else 16.0) * flop / (tot_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
-                "mfma_util_source": "analytic: MFMA FLOPs issued (3 fp16 products per fp32 product) / HIP-event duration / 2.5 PFLOP/s dense",
+                "mfma_util_source": "analytic: MFMA FLOPs issued (3 fp16 products per fp32 product) / HIP-event duration / 2.5 PFLOP/s dense "
+                                    "(tools/ubench/mfma_chain.hip: with random-mantissa operands the matrix pipe sustains 1.73 PFLOP/s — its clock is "
+                                    "data-dependent; against that rate the figure is x1.45)",
             }
             res["roofline_shapes"] = {
                 k_: {"launches_per_denoise_step": v["launches_per_denoise_step"], "avg_launch_ms": v["ms"] / v["launches_per_denoise_step"],
@@ -361,7 +364,10 @@ def main():
                 "frac": fl / (m_a * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "mfma_util": 3.0 * fl / (m_a * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
                 "avg_launch_ms": m_a, "launches_timed": c_a, "traffic": None,
                 "kernel": f"ccdm::k_attention_mfma (engine op {attn}, {eng.op_names[attn]}: T={o['T']}, C={o['C']}, {o['heads']} heads of {o['C'] // o['heads']})",
-                "note": "frac = algorithmic FLOPs (4*T*T*C per sample) over the dense fp16 MFMA peak; mfma_util counts the 3 fp16 MFMAs each product is made of; " + tap_note}
+                "mfma_util_vs_measured_rate": 3.0 * fl / (m_a * 1e-3) / 1e12 / MFMA_MEASURED_TFLOPS,
+                "note": "frac = algorithmic FLOPs (4*T*T*C per sample) over the dense fp16 MFMA peak; mfma_util counts the 3 fp16 MFMAs each product is made of; "
+                        "mfma_util_vs_measured_rate prices them against the 1.73 PFLOP/s the matrix pipe sustains on random-mantissa operands "
+                        "(tools/ubench/mfma_chain.hip: the MFMA clock is data-dependent); " + tap_note}
         per_op = []
         for i, o in enumerate(info):
             cnt, m, lo, hi = taps[i]
