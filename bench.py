@@ -158,7 +158,7 @@ def main():
     ap.add_argument("--denoise-steps", type=int, default=0, help="strided walk of this many denoise steps instead of the full T (diagnostics; not the metric)")
     ap.add_argument("--substreams", type=int, default=-1,
                     help="sample the per-GPU batch as this many contiguous sub-batches on concurrent HIP streams (results are bit-identical); "
-                         "0 = automatic (two from 32 samples up).  Default: the product default (automatic)")
+                         "0 = automatic (two once the batch holds 32 x 128x128 pixels).  Default: the product default (automatic)")
     ap.add_argument("--rng", choices=["philox", "torch_cpu"], default="philox",
                     help="philox: noise generated in the epilogue kernel (the benchmark); torch_cpu: the parity mode — Exp(1) noise drawn "
                          "on the host in the reference's order and copied over PCIe (host-RNG bound; reported for DESIGN.md, never the headline)")
@@ -178,6 +178,7 @@ def main():
 
     from ccdm_stochastic_segmentation_amd import build_model, make_synthetic_state_dict, hip
     from ccdm_stochastic_segmentation_amd.distributed import init_from_env, all_gather_shards
+    from ccdm_stochastic_segmentation_amd.models import auto_substreams
     import torch.distributed as dist
 
     rank, local_rank, world = init_from_env()
@@ -206,7 +207,7 @@ def main():
     model.sample_offset = rank * n                                # Philox counters keyed by global sample index
     model.slicing = args.slicing
     use_graph, substreams = bool(model.use_graph), int(model.substreams)
-    nsub = substreams if substreams > 0 else (2 if n >= 32 else 1)
+    nsub = substreams if substreams > 0 else auto_substreams(n, cfg["H"], cfg["W"])
     nsub = max(1, min(nsub, n))
 
     rng = np.random.default_rng(1234)

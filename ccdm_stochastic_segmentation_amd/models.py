@@ -256,6 +256,11 @@ class UNetModel(nn.Module):
 HOST_NOISE_BLOCK_BYTES = 256 << 20
 
 
+def auto_substreams(N: int, H: int, W: int) -> int:
+    """`substreams = 0`: how many concurrent sub-batch streams a batch of N samples of H x W is sampled on."""
+    return 2 if (N >= 2 and N * H * W >= 32 * 128 * 128) else 1
+
+
 class DenoisingModel(nn.Module):
     """The sampler.  `rng` selects where the Exp(1) noise of the categorical draws comes from:
     "philox" (default) — Philox4x32-10 inside the epilogue kernel, keyed by (pixel, global sample index, step) under a 64-bit key
@@ -287,7 +292,7 @@ class DenoisingModel(nn.Module):
         # each denoise step is replayed as one captured HIP graph (identical results to eager launches, tested)
         self.use_graph = True
         # the batch is sampled as this many contiguous sub-batches on concurrent HIP streams (bit-identical samples).  0 (default) =
-        # automatic: two from 32 samples up (+7-10 % at N = 64: the low-resolution kernels of one half run beside the full-width
+        # automatic: two once the batch holds as many pixels as 32 samples of 128x128 (+7-10 % at N = 64: the low-resolution kernels of one half run beside the full-width
         # kernels of the other), one below.  bench.py times this default and collects its per-kernel taps in a separate
         # single-stream pass (under concurrency a launch's duration no longer describes the kernel).
         self.substreams = 0
@@ -476,7 +481,9 @@ class DenoisingModel(nn.Module):
         # fill a fraction of the GPU; two sub-batches half a step apart fill each other's gaps.  Nothing a sample sees
         # depends on the split (statistics are per sample, slices are a function of the spatial size only, noise is keyed
         # by the global sample index or sliced from the full-batch host draw): the results are bit-identical.
-        nsub = int(self.substreams) if int(self.substreams) > 0 else (2 if N >= 32 else 1)
+        # automatic: two sub-batches once the batch holds as many pixels as 32 LIDC samples (N >= 32 at 128x128; the Cityscapes-shaped
+        # batches of 16 x 256x512 and 4 x 512x1024 qualify: +2.3 % / +2.0 % measured), one below
+        nsub = int(self.substreams) if int(self.substreams) > 0 else auto_substreams(N, H, W)
         nsub = max(1, min(nsub, N))
         bounds = [(N * j) // nsub for j in range(nsub + 1)]
         parts = []
