@@ -1183,7 +1183,7 @@ int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
         CCDM_CHECK_LAUNCH("conv1x1");
         return 0;
     }
-    if (!up2 && !a.fine_slices && conv_ks_eligible(a, k.slices)) {   // few-pixel images: K split over the waves, weight fragments straight from L2
+    if (!up2 && !a.fine_slices && !exp_env("CCDM_NO_KS") && conv_ks_eligible(a, k.slices)) {   // few-pixel images: K split over the waves, weight fragments straight from L2
         const int rck = launch_conv_ks(a, k.slices, k.ntiles, k.wscale, s);
         if (rck) return rck;
         CCDM_CHECK_LAUNCH("conv_ks");
