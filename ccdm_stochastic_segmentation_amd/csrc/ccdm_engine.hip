@@ -12,6 +12,23 @@ namespace ccdm {
 
 __global__ void k_step_set(int32_t* p, int32_t v) { *p = v; }
 __global__ void k_step_inc(int32_t* p) { *p += 1; }
+// the per-run epilogue fields travel as a kernel argument into their device-resident block (stream-ordered: launches already in
+// flight have read the old values, later ones see the new)
+__global__ void k_run_set(ccdm_post_run* dst, const ccdm_post_run v) { *dst = v; }
+// largest |x| of a flat fp32 buffer (Inf if a value is not finite): the attention core's qkv operand in the range diagnostics
+__global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ x, size_t n4, float* out) {
+    float m = 0.f;
+    bool bad = false;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        bad |= !(fabsf(v.x) <= 3.0e38f) | !(fabsf(v.y) <= 3.0e38f) | !(fabsf(v.z) <= 3.0e38f) | !(fabsf(v.w) <= 3.0e38f);
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    if (bad) m = __builtin_inff();
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(m));
+}
 
 struct Op {
     int kind;   // 0 conv, 1 attention core, 2 statistics fold, 3 GroupNorm + qkv + attention core, 4 resample (updown ResBlocks)
@@ -39,11 +56,17 @@ struct ccdm_engine {
     std::vector<ccdm::Op> ops;
     ccdm_post_args post{};
     bool has_post = false;
+    // per-run epilogue fields: host copy, and the device block the epilogue kernel reads them from (NULL: they are kernel arguments)
+    ccdm_post_run run{};
+    ccdm_post_run* run_dev = nullptr;
+    bool run_dirty = false;
+    int next_row = 0;            // where the device step counter stands after the last run (first_row + n_steps)
     // graph of one step (ops + epilogue + counter increment)
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     bool graph_valid = false;
     int graph_with_epilogue = -1;
+    int captures = 0;            // how often the step has been captured and instantiated (tests: a new Philox key must not re-capture)
     // timing taps: HIP events around every launch of the tapped ops (op index -> events, launches recorded)
     struct Tap { std::vector<hipEvent_t> ev; int n = 0; };
     std::map<int, Tap> taps;
@@ -57,9 +80,36 @@ static void drop_graph(ccdm_engine* e) {
     e->graph_valid = false;
 }
 
+#ifdef CCDM_EXPERIMENTS
+// sensitivity probe (experiments builds only; results are garbage): CCDM_SKIP_OPS="a-b,c,d-e" leaves those ops of the step out, to see
+// how much of the step time — in whatever launch mode — a stage is worth before anyone rewrites its kernels
+static bool exp_skip_op(size_t i) {
+    static std::vector<std::pair<int, int>> ranges;
+    static bool parsed = false;
+    if (!parsed) {
+        parsed = true;
+        const char* v = getenv("CCDM_SKIP_OPS");
+        while (v && *v) {
+            char* end;
+            const int a = (int)strtol(v, &end, 10);
+            int b = a;
+            if (*end == '-') b = (int)strtol(end + 1, &end, 10);
+            ranges.push_back({a, b});
+            v = *end == ',' ? end + 1 : end;
+            if (end == v && *v) break;
+        }
+    }
+    for (auto& r : ranges) if ((int)i >= r.first && (int)i <= r.second) return true;
+    return false;
+}
+#endif
+
 static int launch_step(ccdm_engine* e, int with_epilogue, hipStream_t s, bool profile) {
     for (size_t i = 0; i < e->ops.size(); ++i) {
         const Op& op = e->ops[i];
+#ifdef CCDM_EXPERIMENTS
+        if (exp_skip_op(i)) continue;
+#endif
         ccdm_engine::Tap* tp = nullptr;
         if (profile) {
             auto it = e->taps.find((int)i);
@@ -156,10 +206,33 @@ extern "C" int ccdm_engine_set_epilogue(ccdm_engine* e, const ccdm_post_args* a)
 }
 
 extern "C" int ccdm_engine_num_ops(const ccdm_engine* e) { return e ? (int)e->ops.size() : -1; }
+extern "C" int ccdm_engine_num_captures(const ccdm_engine* e) { return e ? e->captures : -1; }
+
+extern "C" int ccdm_engine_set_run_block(ccdm_engine* e, void* dev_block) {
+    CCDM_REQUIRE(e && e->has_post, "engine_set_run_block: no epilogue set");
+    CCDM_REQUIRE(dev_block && (reinterpret_cast<uintptr_t>(dev_block) & 7) == 0, "engine_set_run_block: null or misaligned block");
+    e->run_dev = static_cast<ccdm_post_run*>(dev_block);
+    e->post.run = e->run_dev;
+    const ccdm_post_args& p = e->post;
+    e->run = ccdm_post_run{p.noise, p.noise_step_stride, p.philox_seed, p.sample_offset, p.noise_row0, p.out_probs, p.out_onehot, p.posterior_out};
+    e->run_dirty = true;
+    drop_graph(e);
+    return 0;
+}
 
 extern "C" int ccdm_engine_set_run(ccdm_engine* e, const float* noise, int64_t noise_step_stride, int32_t noise_row0, uint64_t philox_seed,
                                    uint32_t sample_offset, float* out_probs, int64_t* out_onehot, float* posterior_out) {
     CCDM_REQUIRE(e && e->has_post, "engine_set_run: no epilogue set");
+    if (e->run_dev) {
+        // device-resident fields: the captured graph does not depend on them; the block is rewritten at the head of the next run
+        const ccdm_post_run r{noise, noise_step_stride, philox_seed, sample_offset, noise_row0, out_probs, out_onehot, posterior_out};
+        const ccdm_post_run& o = e->run;
+        const bool same = o.noise == r.noise && o.noise_step_stride == r.noise_step_stride && o.philox_seed == r.philox_seed &&
+                          o.sample_offset == r.sample_offset && o.noise_row0 == r.noise_row0 && o.out_probs == r.out_probs &&
+                          o.out_onehot == r.out_onehot && o.posterior_out == r.posterior_out;
+        if (!same) { e->run = r; e->run_dirty = true; }
+        return 0;
+    }
     ccdm_post_args& p = e->post;
     const bool same = p.noise == noise && p.noise_step_stride == noise_step_stride && p.noise_row0 == noise_row0 && p.philox_seed == philox_seed &&
                       p.sample_offset == sample_offset && p.out_probs == out_probs && p.out_onehot == out_onehot &&
@@ -176,6 +249,12 @@ extern "C" int ccdm_engine_run(ccdm_engine* e, int first_row, int n_steps, int w
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_step_set, dim3(1), dim3(1), 0, s, e->step, (int32_t)first_row);
     CCDM_CHECK_LAUNCH("step_set");
+    e->next_row = first_row + n_steps;
+    if (e->run_dev && e->run_dirty) {
+        hipLaunchKernelGGL(k_run_set, dim3(1), dim3(1), 0, s, e->run_dev, e->run);
+        CCDM_CHECK_LAUNCH("run_set");
+        e->run_dirty = false;
+    }
     const bool profile = !e->taps.empty();
     if (profile) {
         use_graph = 0;
@@ -194,6 +273,7 @@ extern "C" int ccdm_engine_run(ccdm_engine* e, int first_row, int n_steps, int w
             if (err != hipSuccess) return fail("engine_run: GraphInstantiate: %s", hipGetErrorString(err));
             e->graph_valid = true;
             e->graph_with_epilogue = with_epilogue;
+            e->captures++;
         }
         for (int i = 0; i < n_steps; ++i) {
             hipError_t err = hipGraphLaunch(e->exec, s);
@@ -246,14 +326,27 @@ extern "C" int ccdm_engine_profile_read(ccdm_engine* e, int op_index, double* me
     return n;
 }
 
-extern "C" int ccdm_engine_input_absmax(ccdm_engine* e, float* out, void* stream) {
+extern "C" int ccdm_engine_input_absmax(ccdm_engine* e, float* out, int row, void* stream) {
     CCDM_REQUIRE(e && out, "engine_input_absmax: null");
-    for (size_t i = 0; i < e->ops.size(); ++i) {
-        if (e->ops[i].kind != 0) continue;
-        const int rc = launch_conv_input_absmax(e->ops[i].conv, out + i, (hipStream_t)stream);
-        if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    // the activations were produced with table row `row` (default: the last one the last run executed); the counter stands one past it
+    const int r = row >= 0 ? row : (e->next_row > 0 ? e->next_row - 1 : 0);
+    hipLaunchKernelGGL(k_step_set, dim3(1), dim3(1), 0, s, e->step, (int32_t)r);
+    CCDM_CHECK_LAUNCH("step_set");
+    int rc = 0;
+    for (size_t i = 0; i < e->ops.size() && !rc; ++i) {
+        const Op& op = e->ops[i];
+        if (op.kind == 0) rc = launch_conv_input_absmax(op.conv, out + i, s);
+        else if (op.kind == 1) {
+            const size_t n4 = (size_t)op.N * op.T * 3 * op.C / 4;
+            const unsigned bx = (unsigned)(n4 / 256 < 1 ? 1 : (n4 / 256 > 1024 ? 1024 : n4 / 256));
+            hipLaunchKernelGGL(k_absmax, dim3(bx), dim3(256), 0, s, op.qkv, n4, out + i);
+            if (hipGetLastError() != hipSuccess) rc = fail("engine_input_absmax: attention operand probe failed to launch");
+        }
     }
-    return 0;
+    hipLaunchKernelGGL(k_step_set, dim3(1), dim3(1), 0, s, e->step, (int32_t)e->next_row);
+    CCDM_CHECK_LAUNCH("step_set");
+    return rc;
 }
 
 extern "C" int ccdm_engine_describe_op(const ccdm_engine* e, int i, char* buf, int buflen) {

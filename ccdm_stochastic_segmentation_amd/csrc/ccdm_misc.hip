@@ -146,7 +146,7 @@ int launch_attention(const float* qkv, float* out, int N, int T, int Ta, int C, 
     CCDM_REQUIRE(heads > 0 && C % heads == 0, "attention: C=%d not divisible by heads=%d", C, heads);
     CCDM_REQUIRE(T > 0 && Ta >= T, "attention: T=%d, %d rows allocated per sample", T, Ta);
     const int D = C / heads;
-    const bool force_valu = (order & 256) != 0;       // test hook: bit 8 selects the VALU kernel
+    const bool force_valu = (order & CCDM_ATTENTION_FORCE_VALU) != 0;       // the exact-fp32 vector-pipe kernel (range fallback, tests)
     order &= 255;
     // Matrix-core kernel: every head width that is a multiple of 4 up to 128 (padded to 32 / 64 / 96 / 128 inside).  Head width 32 with
     // a token count that is not a multiple of 32 keeps the VALU kernel it has always run on (round-1 behaviour, bit for bit).

@@ -36,7 +36,14 @@ __device__ __forceinline__ float u32_to_exp1(uint32_t bits) {
 }
 
 template <int KP>
-__global__ __launch_bounds__(256) void k_posterior(const ccdm_post_args a) {
+__global__ __launch_bounds__(256) void k_posterior(const ccdm_post_args a_in) {
+    // per-run fields: from the device-resident block when there is one (uniform scalar loads), else the arguments themselves
+    ccdm_post_args a = a_in;
+    if (a_in.run) {
+        const ccdm_post_run r = *a_in.run;
+        a.noise = r.noise; a.noise_step_stride = r.noise_step_stride; a.philox_seed = r.philox_seed; a.sample_offset = r.sample_offset;
+        a.noise_row0 = r.noise_row0; a.out_probs = r.out_probs; a.out_onehot = r.out_onehot; a.posterior_out = r.posterior_out;
+    }
     const size_t npix = (size_t)a.N * a.HW;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npix) return;

@@ -267,7 +267,13 @@ class SamplerEngine:
 
     def _attn(self, p: str, l, x: DevTensor) -> DevTensor:
         T_ = x.h * x.w
-        fused = (self.prec == hip.PREC_F16X3 and (p + ".qkv") not in self.f32_layers and x.stats is not None and not os.environ.get("CCDM_NO_ATTN_BLOCK")
+        # pinned to exact fp32 by the range fallback: "<block>.qkv" = the qkv conv, "<block>.attention" = the core (its own fp16 split
+        # stages q, k, v: the vector-pipe kernel computes the same softmax(q k^T) v in plain fp32 FMAs for head widths it is built for)
+        # An exact-fp32 engine (validation mode, the range fallback's diagnosing re-run) takes that kernel too, up to 2048 tokens — its
+        # cost grows with T^2 on the vector pipe; beyond, the core keeps the matrix kernel and its operand range.
+        core_f32 = (p + ".attention") in self.f32_layers or (self.prec == hip.PREC_F32 and T_ <= 2048)
+        fused = (self.prec == hip.PREC_F16X3 and (p + ".qkv") not in self.f32_layers and not core_f32 and x.stats is not None
+                 and not os.environ.get("CCDM_NO_ATTN_BLOCK")
                  and self.lib.ccdm_norm_qkv_attention_supported(T_, l.ch, l.heads))
         if fused:
             # GroupNorm + qkv + attention core in one launch (low-resolution stages): the 3C-wide qkv tensor stays on chip
@@ -291,8 +297,11 @@ class SamplerEngine:
             return self._conv([att], p + ".proj_out", l.ch, 1, resid=x)
         qkv = self._conv([x], p + ".qkv", 3 * l.ch, 1, gn=p + ".norm", act=hip.ACT_NONE, stats=False)
         a = self._act(l.ch, x.h, x.w, False)
-        hip.check(self.lib.ccdm_engine_add_attention(self._handle, qkv.ptr, a.ptr, self.N, x.h * x.w, l.ch, l.heads,
-                                                     1 if l.new_order else 0), "engine_add_attention")
+        order = 1 if l.new_order else 0
+        if core_f32 and (l.ch // l.heads) in hip.ATTENTION_VALU_WIDTHS:
+            order |= hip.ATTENTION_FORCE_VALU
+        hip.check(self.lib.ccdm_engine_add_attention(self._handle, qkv.ptr, a.ptr, self.N, x.h * x.w, l.ch, l.heads, order),
+                  "engine_add_attention")
         self.op_names.append(p + ".attention")
         self.op_info.append(dict(kind="attention", name=p + ".attention", T=T_, C=l.ch, heads=l.heads, io_bytes=4 * 4 * l.ch * T_,
                                  gn_read_bytes=0, weight_bytes=0, flop=4 * T_ * T_ * l.ch))
@@ -414,8 +423,13 @@ class SamplerEngine:
         post.noise_row0, post.range_flag = 0, self.flag.data_ptr()
         self._post = post
         hip.check(lib.ccdm_engine_set_epilogue(self._handle, C.byref(post)), "engine_set_epilogue")
+        # the per-run epilogue fields (Philox key, noise block, output pointers) live in a device block the kernel reads, like the step
+        # counter: a new key per sampling call or a new host-noise block does not re-capture the step's graph
+        self.run_block = self._dev((hip.POST_RUN_BYTES // 8,), torch.int64, zero=True)
+        hip.check(lib.ccdm_engine_set_run_block(self._handle, self.run_block.data_ptr()), "engine_set_run_block")
         self._sd = None   # host copies no longer needed
         self._tables_key = None
+        self._per_sample_rows = False
 
     def __del__(self):
         try:
@@ -437,6 +451,11 @@ class SamplerEngine:
     def leave(self) -> None:
         """Order the caller's current stream after everything launched on the engine's stream."""
         torch.cuda.current_stream(self.device).wait_stream(self.stream)
+
+    def graph_captures(self) -> int:
+        """How often the step's HIP graph has been captured so far (a change of the Philox key, the noise block or an output pointer must
+        not add to it: those travel through the device-resident run block)."""
+        return int(self.lib.ccdm_engine_num_captures(self._handle))
 
     def describe_ops(self) -> List[str]:
         out = []
@@ -481,6 +500,7 @@ class SamplerEngine:
             tab[i, 0], tab[i, 1], tab[i, 2] = a, c, float(mode)
         self.step_table[:S].copy_(tab)
         self.rowmap.copy_(torch.arange(self.N, dtype=torch.int32) if per_sample else torch.zeros(self.N, dtype=torch.int32))
+        self._per_sample_rows = bool(per_sample)
         w0, b0, w2, b2 = (t.data_ptr() for t in self.te)
         hip.check(self.lib.ccdm_time_table(self.sinus.data_ptr(), S, self.spec.model_channels, w0, b0, w2, b2,
                                            self.wcat.data_ptr(), self.bcat.data_ptr(), self.E, 0,
@@ -510,25 +530,50 @@ class SamplerEngine:
             return None
         return self.head_ce.buf[..., : self.K - 1].clone().permute(0, 3, 1, 2)
 
-    def input_absmax(self) -> Dict[str, float]:
+    def probe_buffer(self) -> torch.Tensor:
+        """A zeroed device buffer for `probe_ranges` (one float per op), created on the engine's stream."""
+        with self.enter():
+            buf = torch.zeros((self.n_unet_ops,), dtype=torch.float32, device=self.device)
+        self.leave()
+        return buf
+
+    def probe_ranges(self, buf: torch.Tensor, row: int = -1) -> None:
+        """Enqueue the F16X3 range diagnostics of the tensors the last run left behind (no synchronisation): buf[i] = max(buf[i], largest
+        |a| op i stages).  `row` = the step-table row those activations were produced with (-1: the last row the last run executed —
+        the device counter itself stands one past it, and FiLM's scale / shift are read from that row)."""
+        rows = self.N if self._per_sample_rows else 1
+        r = int(row)
+        if r >= 0 and r + rows > self.max_steps:
+            raise ValueError(f"probe_ranges: row {r} (+{rows - 1} per-sample rows) lies beyond the {self.max_steps}-row tables")
+        with self.enter():
+            hip.check(self.lib.ccdm_engine_input_absmax(self._handle, buf.data_ptr(), r, self._stream()), "engine_input_absmax")
+        self.leave()
+
+    def read_ranges(self, buf: torch.Tensor) -> Dict[str, float]:
+        """Synchronises; op name -> largest staged |a| (Inf if a value was not finite) for the conv ops and the attention cores."""
+        with self.enter():
+            vals = buf.cpu().tolist()
+        self.leave()
+        return {self.op_names[i]: float(vals[i]) for i in range(self.n_unet_ops) if self.op_info[i]["kind"] in ("conv", "attention")}
+
+    def input_absmax(self, row: int = -1) -> Dict[str, float]:
         """F16X3 range diagnostics on the tensors the last run left behind (synchronises): for every conv op its state_dict prefix ->
-        the largest |a| it stages (include/ccdm_hip.h: ccdm_conv_input_absmax; Inf if a value is not finite).  Meaningful on an engine
-        whose values are trustworthy — the exact-fp32 one, or an F16X3 one that did not overflow."""
-        n = self.n_unet_ops
-        buf = torch.zeros((n,), dtype=torch.float32, device=self.device)
-        with torch.cuda.stream(self.stream):
-            hip.check(self.lib.ccdm_engine_input_absmax(self._handle, buf.data_ptr(), self._stream()), "engine_input_absmax")
-        self.stream.synchronize()
-        vals = buf.cpu().tolist()
-        return {self.op_names[i]: float(vals[i]) for i in range(n) if self.op_info[i]["kind"] == "conv"}
+        the largest |a| it stages (include/ccdm_hip.h: ccdm_conv_input_absmax; Inf if a value is not finite); for an attention core
+        ("<block>.attention") the largest |q|, |k|, |v|.  Meaningful on an engine whose values are trustworthy — the exact-fp32 one, or an
+        F16X3 one that did not overflow."""
+        buf = self.probe_buffer()
+        self.probe_ranges(buf, row)
+        return self.read_ranges(buf)
 
     def check_and_clear_flag(self) -> bool:
         """Synchronises with the engine's stream; True (and the flag cleared) if any head output of the runs since the last check was
-        not finite."""
-        if int(self.flag.item()) != 0:
-            self.flag.zero_()
-            return True
-        return False
+        not finite.  Read and reset on the engine's own stream: the epilogue that raises the flag runs there."""
+        with self.enter():
+            hit = int(self.flag.item()) != 0
+            if hit:
+                self.flag.zero_()
+        self.leave()
+        return hit
 
     def raise_range_error(self) -> None:
         raise hip.CcdmRangeError(

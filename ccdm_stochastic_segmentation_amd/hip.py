@@ -26,13 +26,15 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 
 ACT_NONE, ACT_SILU = 0, 1
 RESAMPLE_AVGPOOL2, RESAMPLE_NEAREST_UP2 = 0, 1      # CCDM_RESAMPLE_*
+ATTENTION_FORCE_VALU = 256          # bit 8 of ccdm_attention's `order`: the vector-pipe kernel (plain fp32 FMAs) instead of the matrix cores
+ATTENTION_VALU_WIDTHS = (4, 8, 12, 16, 24, 32, 48, 64)      # head widths that kernel is instantiated for
 DIAG_GENERAL_KERNEL = 2048 << 8     # CCDM_DIAG_GENERAL_KERNEL: OR into ConvArgs.prec to bypass the specialised conv kernels (parity tests)
 PREC_F32, PREC_F16X3 = 0, 1
 STEP_SAMPLE, STEP_LAST_CONFIDENCE, STEP_LAST_MAJORITY, STEP_LAST_KEEP, STEP_SOFTMAX_ONLY = 0, 1, 2, 3, 4
 STATS_MAX_SLICES = 64       # CCDM_STATS_MAX_SLICES: what a GroupNorm consumer reads
 F16X3_LIMIT = 4094.0        # CCDM_F16X3_LIMIT: the fp16 split is exact for staged |a| below this
 STATS_FOLD_SLICES = 16      # CCDM_STATS_FOLD_SLICES: what the engine folds a larger slice count to
-ABI_VERSION = 6          # CCDM_ABI_VERSION of include/ccdm_hip.h
+ABI_VERSION = 7          # CCDM_ABI_VERSION of include/ccdm_hip.h
 
 
 class ConvArgs(C.Structure):
@@ -72,7 +74,11 @@ class PostArgs(C.Structure):
         ("posterior_out", C.c_void_p),
         ("noise_row0", C.c_int32),
         ("range_flag", C.c_void_p),
+        ("run", C.c_void_p),
     ]
+
+
+POST_RUN_BYTES = 56      # sizeof(ccdm_post_run): the device-resident per-run fields of the epilogue
 
 
 class AttnBlockArgs(C.Structure):
@@ -108,7 +114,7 @@ SIGNATURES = {
     "ccdm_pack_upconv_weight": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ccdm_conv2d": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "ccdm_conv_input_absmax": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p, C.c_void_p]),
-    "ccdm_engine_input_absmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ccdm_engine_input_absmax": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "ccdm_stats_fold": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ccdm_norm_qkv_attention_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "ccdm_norm_qkv_attention": (C.c_int, [C.POINTER(AttnBlockArgs), C.c_void_p]),
@@ -138,6 +144,8 @@ SIGNATURES = {
     "ccdm_engine_add_attention": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ccdm_engine_set_epilogue": (C.c_int, [C.c_void_p, C.POINTER(PostArgs)]),
     "ccdm_engine_num_ops": (C.c_int, [C.c_void_p]),
+    "ccdm_engine_num_captures": (C.c_int, [C.c_void_p]),
+    "ccdm_engine_set_run_block": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ccdm_engine_set_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ccdm_engine_run": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ccdm_engine_profile_op": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),

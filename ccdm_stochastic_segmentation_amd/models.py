@@ -384,16 +384,29 @@ class DenoisingModel(nn.Module):
     def _to_index(x: Tensor, device) -> Tensor:
         return x.argmax(dim=1).to(device=device, dtype=torch.uint8).contiguous()
 
-    # staged values within this factor of hip.F16X3_LIMIT pin a layer to fp32 (the probe sees two steps of one call, not every input)
+    # staged values within this factor of hip.F16X3_LIMIT pin a layer to fp32 (the probe sees the steps of one call, not every input)
     RANGE_MARGIN = 0.5
 
     def _probe_ranges(self, engines) -> None:
-        """diagnosing fp32 re-run: fold what every conv of these (exact-fp32) engines staged in its last step into the probe"""
+        """diagnosing fp32 re-run: fold what every conv / attention core of these (exact-fp32) engines staged in the step they just ran
+        into the probe — enqueued on the engine's stream into a device buffer per engine (a running maximum over all steps of the call),
+        read once at the end (`_collect_probe`)"""
         if self._range_probe is None:
             return
         for eng in engines:
-            for name, v in eng.input_absmax().items():
-                self._range_probe[name] = max(self._range_probe.get(name, 0.0), v)
+            hit = self._range_probe.get(id(eng))
+            if hit is None:
+                hit = self._range_probe[id(eng)] = (eng, eng.probe_buffer())
+            eng.probe_ranges(hit[1])
+
+    def _collect_probe(self) -> Optional[Dict[str, float]]:
+        if self._range_probe is None:
+            return None
+        out: Dict[str, float] = {}
+        for eng, buf in self._range_probe.values():
+            for name, v in eng.read_ranges(buf).items():
+                out[name] = max(out.get(name, 0.0), v)
+        return out
 
     def _with_range_fallback(self, fn):
         if self.on_range_error not in ("layers", "f32", "raise"):
@@ -409,19 +422,32 @@ class DenoisingModel(nn.Module):
                 torch.set_rng_state(state)
             prec, self.prec = self.prec, hip.PREC_F32
             self._range_probe = {} if self.on_range_error == "layers" else None
+            probe = None
             try:
                 out = fn()
+                probe = self._collect_probe()
             finally:
                 self.prec = prec
-                probe, self._range_probe = self._range_probe, None
-            if probe:
+                self._range_probe = None
+            if probe is not None:
                 limit = hip.F16X3_LIMIT * self.RANGE_MARGIN
                 hot = sorted(k for k, v in probe.items() if not (v < limit))
                 new = [k for k in hot if k not in self.f32_layers]
                 if new:
                     self.f32_layers.update(new)
-                    LOGGER.warning("F16X3 range: %d conv layer(s) stage values beyond %.0f (%s ...); they run the exact-fp32 kernels from now on "
+                    LOGGER.warning("F16X3 range: %d layer(s) stage values beyond %.0f (%s ...); they run the exact-fp32 kernels from now on "
                                    "(DenoisingModel.f32_layers)", len(new), limit, ", ".join(new[:4]))
+                    # the engines built for the old pin set and the diagnosing all-fp32 ones are dead weight now — at Cityscapes-sized
+                    # batches three activation sets per sub-batch slot is what runs a GPU out of memory exactly when the fallback triggers
+                    self._engines.clear()
+                else:
+                    # an overflow the probe cannot attribute to a pinnable layer (every step of this call was looked at): without a
+                    # new pin every later call would run F16X3, overflow and be repeated in fp32 — about 5x the cost, forever
+                    LOGGER.warning("F16X3 range: the overflow could not be attributed to a layer (largest staged value %.3g); this model "
+                                   "runs the exact-fp32 kernels from now on (DenoisingModel.prec = PREC_F32)",
+                                   max(probe.values()) if probe else float("nan"))
+                    self.prec = hip.PREC_F32
+                    self._engines = {k: v for k, v in self._engines.items() if k[6] == hip.PREC_F32}
             return out
 
     def forward_step(self, x: Tensor, condition: Tensor, feature_condition: Tensor, t: Tensor) -> dict:
@@ -504,8 +530,8 @@ class DenoisingModel(nn.Module):
             blocks = [(s0, min(s0 + blk, S)) for s0 in range(0, S, blk)]
         else:
             blocks = [(0, S)]
-        if self._range_probe is not None and S > 1:      # diagnosing fp32 re-run: look at the first step's activations too
-            blocks = [(0, 1)] + [(max(s0, 1), s1) for s0, s1 in blocks if s1 > 1]
+        if self._range_probe is not None:      # diagnosing fp32 re-run: one step per block, every step's activations are probed
+            blocks = [(s, s + 1) for s in range(S)]
         for s0, s1 in blocks:
             noises: List[Optional[Tensor]] = [None] * nsub
             if host_rng:

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define CCDM_ABI_VERSION 6
+#define CCDM_ABI_VERSION 7
 #define CCDM_MAX_CHANNELS 1024      /* max C0+C1 of a GroupNorm'ed conv input */
 #define CCDM_STATS_MAX_SLICES 64    /* partial-statistics slices per sample a GroupNorm consumer reads (more: ccdm_stats_fold) */
 #define CCDM_STATS_FOLD_SLICES 16   /* what ccdm_stats_fold reduces a larger slice count to */
@@ -165,7 +165,11 @@ size_t ccdm_pack_conv_weight_ex(const float* oihw, int Cout, int Cin, int ksize,
  * qkv: [N,T,3C] (the qkv 1x1 conv output, NHWC), out: [N,T,C].
  * order 0 = QKVAttentionLegacy (channel = head*3ch + {q,k,v}*ch + c, unet.py:343-360),
  * order 1 = QKVAttention        (channel = {q,k,v}*C + head*ch + c,   unet.py:376-395).
+ * order | CCDM_ATTENTION_FORCE_VALU: the vector-pipe kernel (plain fp32 FMAs, head widths 4, 8, 12, 16, 24, 32, 48, 64) instead of the
+ * matrix-core one, whose fp16 hi/lo split of q, k, v has the range of CCDM_PREC_F16X3 — what the host pins an attention core to
+ * whose operands left that range ("<block>.attention" in DenoisingModel.f32_layers).
  * ------------------------------------------------------------------------------------------------- */
+#define CCDM_ATTENTION_FORCE_VALU 256
 int ccdm_attention(const float* qkv, float* out, int N, int T, int C, int heads, int order, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
@@ -214,6 +218,16 @@ int ccdm_time_table(const float* sinus /*dev [S,mc]*/, int S, int model_channels
 enum { CCDM_STEP_SAMPLE = 0, CCDM_STEP_LAST_CONFIDENCE = 1, CCDM_STEP_LAST_MAJORITY = 2, CCDM_STEP_LAST_KEEP = 3,
        CCDM_STEP_SOFTMAX_ONLY = 4 /* out_probs = x0 (the U-Net output itself): forward_step, diffusion_denoising.py:161-162 */ };
 
+/* The per-run fields of the epilogue as a DEVICE-resident block (ABI 7).  With ccdm_post_args.run set the kernel reads these eight
+ * values from the block instead of the argument struct, like it reads the step row through step_ptr: a captured HIP graph of the
+ * denoise step then survives a new Philox key, another noise buffer or another output pointer (the host rewrites the block with
+ * a stream-ordered one-thread launch; nothing is re-captured, nothing is destroyed while earlier launches are in flight). */
+typedef struct ccdm_post_run {
+    const float* noise; int64_t noise_step_stride;
+    uint64_t philox_seed; uint32_t sample_offset; int32_t noise_row0;
+    float* out_probs; int64_t* out_onehot; float* posterior_out;
+} ccdm_post_run;
+
 typedef struct ccdm_post_args {
     const float* head;           /* dev [N,HW,head_stride] head conv output (logits, or probabilities if !softmax), first K channels used */
     int32_t softmax;             /* 1: apply softmax over K first */
@@ -234,6 +248,8 @@ typedef struct ccdm_post_args {
     int32_t noise_row0;          /* step row the first row of `noise` belongs to (host noise uploaded in blocks of steps) */
     int32_t* range_flag;         /* dev scalar or NULL: set to 1 (sticky, never cleared by the kernel) when the head output of
                                     any pixel is not finite — the signature of an F16X3 range overflow upstream (see above) */
+    const ccdm_post_run* run;    /* dev block or NULL: when set, noise / noise_step_stride / noise_row0 / philox_seed / sample_offset /
+                                    out_probs / out_onehot / posterior_out are read from it and the fields above are ignored */
 } ccdm_post_args;
 
 int ccdm_posterior_sample(const ccdm_post_args* a, void* stream);
@@ -304,7 +320,12 @@ int ccdm_engine_add_stats_fold(ccdm_engine* e, const double* in, int N, int S_in
 int ccdm_engine_add_resample(ccdm_engine* e, const ccdm_resample_args* a);
 int ccdm_engine_set_epilogue(ccdm_engine* e, const ccdm_post_args* a);      /* run after the ops of each step */
 int ccdm_engine_num_ops(const ccdm_engine* e);
-/* per-run mutable fields of the epilogue (everything else is fixed at build time) */
+int ccdm_engine_num_captures(const ccdm_engine* e);   /* how often ccdm_engine_run has captured + instantiated the step's HIP graph so far */
+/* per-run mutable fields of the epilogue (everything else is fixed at build time).  With a run block (ccdm_engine_set_run_block:
+ * caller-owned device memory of at least sizeof(ccdm_post_run) bytes, set once before the first run) the values travel to the
+ * device by a one-thread launch at the head of the next ccdm_engine_run, on its stream, and the captured graph of the step stays
+ * valid; without one they are kernel arguments and a change re-captures the graph. */
+int ccdm_engine_set_run_block(ccdm_engine* e, void* dev_block);
 int ccdm_engine_set_run(ccdm_engine* e, const float* noise, int64_t noise_step_stride, int32_t noise_row0,
                         uint64_t philox_seed, uint32_t sample_offset,
                         float* out_probs, int64_t* out_onehot, float* posterior_out);
@@ -316,9 +337,14 @@ int ccdm_engine_run(ccdm_engine* e, int first_row, int n_steps, int with_epilogu
  * mean/min/max in ms. */
 int ccdm_engine_profile_op(ccdm_engine* e, int op_index, int capacity);
 int ccdm_engine_profile_read(ccdm_engine* e, int op_index, double* mean_ms, double* min_ms, double* max_ms);
-/* ccdm_conv_input_absmax of every conv op of the step on the tensors the last run left behind: out[i] = max(out[i], ...) for conv op i
- * (other ops: untouched).  out: dev float [ccdm_engine_num_ops], zeroed by the caller. */
-int ccdm_engine_input_absmax(ccdm_engine* e, float* out, void* stream);
+/* ccdm_conv_input_absmax of every conv op of the step on the tensors the last run left behind: out[i] = max(out[i], ...) for conv op i;
+ * for an attention-core op the largest |q|, |k|, |v| of its qkv tensor (what the core's own fp16 split stages; the fused
+ * norm+qkv+attention op keeps qkv on chip and is not covered: probe an engine that runs the two launches).  Other ops: untouched.
+ * out: dev float [ccdm_engine_num_ops], zeroed by the caller (calls accumulate: max over several steps of a run).
+ * `row`: the step-table row the probed activations were produced with — GroupNorm's FiLM scale / shift are rebuilt from
+ * emb_table[emb_row_of_sample[n] + row]; row < 0 = the last row the last ccdm_engine_run executed (the device counter itself stands
+ * one past it).  The step counter is set to `row` for the probe and put back to where the run left it. */
+int ccdm_engine_input_absmax(ccdm_engine* e, float* out, int row, void* stream);
 /* describe op i: writes a short text ("conv3x3 32->32 @128x128 gn silu ...") */
 int ccdm_engine_describe_op(const ccdm_engine* e, int i, char* buf, int buflen);
 

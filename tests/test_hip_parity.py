@@ -1593,6 +1593,39 @@ def test_conv_input_absmax_matches_torch(U):
     sks[1, 3, 4, 5] = float("nan")
     assert probe(hip.ACT_SILU, True, sks) == float("inf")
 
+    # FiLM (use_scale_shift_norm, unet.py:254-258): GroupNorm's scale / shift come from emb_table row emb_row_of_sample[n] + *step_ptr —
+    # the row the activations were produced with, not wherever a step counter stands afterwards
+    C = 96
+    table = rnd(rng, 5, 2 * C, scale=0.5)
+    tdev, rows = table.to(U.DEV), torch.tensor([1, 0], dtype=torch.int32, device=U.DEV)
+    g, b = gamma.to(U.DEV), beta.to(U.DEV)
+
+    def probe_film(step):
+        a = hip.ConvArgs()
+        a.in0, a.C0, a.in1, a.C1 = srcs[0].data_ptr(), 64, srcs[1].data_ptr(), 32
+        a.stats0, a.slices0, a.stats1, a.slices1 = stats[0].data_ptr(), 2, stats[1].data_ptr(), 2
+        a.gamma, a.beta = g.data_ptr(), b.data_ptr()
+        a.eps, a.act, a.emb_off = 1e-5, hip.ACT_SILU, -1
+        a.film, a.film_off = 1, 0
+        a.emb_table, a.emb_stride, a.emb_row_of_sample = tdev.data_ptr(), 2 * C, rows.data_ptr()
+        sp = torch.tensor([step], dtype=torch.int32, device=U.DEV)
+        a.step_ptr = sp.data_ptr()
+        a.N, a.Hin, a.Win, a.Hout, a.Wout, a.ksize, a.stride, a.Cout, a.prec = N, 16, 16, 16, 16, 3, 1, 32, hip.PREC_F16X3
+        out = torch.zeros(1, device=U.DEV)
+        hip.check(lib.ccdm_conv_input_absmax(C_.byref(a), out.data_ptr(), 0), "conv_input_absmax")
+        U.sync()
+        return out.item()
+
+    def ref_film(step):
+        gn = F.group_norm(x, 32, gamma, beta, 1e-5)
+        r = torch.tensor([1, 0]) + step
+        sc, sh = table[r, :C].reshape(N, C, 1, 1), table[r, C:].reshape(N, C, 1, 1)
+        return F.silu(gn * (1 + sc) + sh).abs().max().item()
+
+    for step in (0, 2, 3):
+        assert abs(probe_film(step) - ref_film(step)) < 1e-4 * ref_film(step), step
+    assert abs(ref_film(0) - ref_film(3)) > 1e-2 * ref_film(0)          # (the rows do differ: the test can tell them apart)
+
 
 def test_trained_like_weights_in_range_stay_on_the_fast_path(U, parity_log):
     """Outlier channels x300 that stay inside the split's window: the F16X3 path itself holds the 1e-4 bar (no fallback)."""
@@ -1614,6 +1647,141 @@ def test_trained_like_weights_in_range_stay_on_the_fast_path(U, parity_log):
     err = (got - ref).abs().max().item()
     parity_log("trained_like_outlier_weights_in_range", max_dp=err, bar=1e-4)
     assert err < 1e-4
+
+
+def test_range_fallback_with_film_probes_the_rows_the_run_executed(U, parity_log):
+    """use_scale_shift_norm network + out-of-range weights.  (1) The engine's range probe rebuilds FiLM's scale / shift from the
+    table row the activations were produced with (the device counter stands one past it; after a full walk of all T rows, or a
+    forward_step with per-sample rows, "one past" lies beyond the tables).  (2) The per-layer fallback of a FULL walk (S == max_steps)
+    looks at every step, pins layers, and the mixed engine reproduces the all-fp32 samples within the free-running bound."""
+    T, N = 4, 2
+    bp = dict(LIDC_BP, use_scale_shift_norm=True)
+    model = build_model(T, "cosine", {"s": 0.008}, [(1, 128, 128), (2, 128, 128)], (1, 128, 128), "unet_openai", bp,
+                        "datasets.lidc", "confidence", None)
+    sd = _trained_like_state_dict(model.unet.spec, 0)
+    model.unet.load_state_dict(sd, strict=True)
+    model = model.to("cuda:0").eval()
+    rng = np.random.default_rng(18)
+    img = torch.from_numpy(rng.uniform(-1, 1, (N, 1, 128, 128)).astype(np.float32)).to(U.DEV)
+    x = O.one_hot_bchw(torch.from_numpy(rng.integers(0, 2, (N, 128, 128))), 2).to(U.DEV)
+    # ---- (1) forward_step with per-sample rows on the exact-fp32 engine
+    model.prec = hip.PREC_F32
+    t = torch.tensor([3.0, 1.0])
+    got = model(x, img, t=t, validation=True)["diffusion_out"].cpu()
+    ref = O.unet_forward(sd, LIDC_CFG, x.cpu(), img.cpu(), None, t)["diffusion_out"]
+    assert (got - ref).abs().max().item() < 1e-4
+    eng = model._engine(x, img, None)
+    p_last, p_row0, p_row1 = eng.input_absmax(), eng.input_absmax(0), eng.input_absmax(1)
+    assert p_last == p_row0                                       # default row = the row the run executed
+    film = [k for k in p_row0 if k.endswith("out_layers.3")]
+    assert film and any(p_row1[k] != p_row0[k] for k in film)     # another row's scale / shift: other staged values
+    assert all(np.isfinite(v) for v in p_row0.values())
+    with pytest.raises(ValueError, match="beyond"):
+        eng.input_absmax(eng.max_steps - 1)                       # per-sample rows n + row would leave the tables
+    # ---- (2) full walk, per-layer fallback
+    model.prec, model.on_range_error, model.rng, model.philox_seed, model.philox_advance = hip.PREC_F16X3, "layers", "philox", 3, False
+    a = model(x, img)["diffusion_out"]                            # t = None: all T rows; overflow -> fp32 re-run, every step probed
+    pinned = set(model.f32_layers)
+    assert len(model._engines) == 0                               # the stale F16X3 and the diagnosing fp32 engines are gone
+    model.prec = hip.PREC_F32
+    b = model(x, img)["diffusion_out"]
+    n_conv = sum(1 for o in model._engine(x, img, None).op_info if o["kind"] == "conv")
+    assert "input_blocks.3.0.op" in pinned and len(pinned) < n_conv // 2, sorted(pinned)
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+    model.prec, model.on_range_error = hip.PREC_F16X3, "raise"
+    c = model(x, img)["diffusion_out"]
+    frac = ((c - b).abs() > 1e-3).float().mean().item()
+    parity_log("film_full_walk_layer_fallback", layers_pinned=len(pinned), frac_gt_1e3=frac)
+    assert torch.isfinite(c).all() and frac <= FREE_RUN_FRAC
+
+
+def test_attention_operand_overflow_is_pinned_to_the_vector_kernel(U, parity_log):
+    """A qkv conv whose OUTPUT leaves the fp16 split's range overflows inside the attention core (its q / k / v staging), not in any
+    conv: the diagnosing fp32 re-run (vector-pipe attention, plain fp32) finds it on "<block>.attention", the pinned engine runs that
+    core on the vector kernel, and the result holds the 1e-4 bar."""
+    model = build_model(250, "cosine", {"s": 0.008}, [(1, 128, 128), (2, 128, 128)], (1, 128, 128), "unet_openai", LIDC_BP,
+                        "datasets.lidc", "confidence", None)
+    sd = {k: torch.from_numpy(v).clone() for k, v in make_synthetic_state_dict(model.unet.spec, 0).items()}
+    blk = "middle_block.1"
+    sd[blk + ".qkv.weight"][64:96] *= 2.0e5                      # v rows of head 0 (legacy order: head*96 + {q,k,v}*32 + d): |v| beyond fp16 (65504)
+    model.unet.load_state_dict(sd, strict=True)
+    model = model.to("cuda:0").eval()
+    rng = np.random.default_rng(19)
+    img = torch.from_numpy(rng.uniform(-1, 1, (2, 1, 128, 128)).astype(np.float32))
+    x = O.one_hot_bchw(torch.from_numpy(rng.integers(0, 2, (2, 128, 128))), 2)
+    t = torch.full((2,), 40.0)
+    ref = O.unet_forward(sd, LIDC_CFG, x, img, None, t)["diffusion_out"]
+    assert torch.isfinite(ref).all()
+    model.on_range_error = "raise"
+    with pytest.raises(hip.CcdmRangeError):
+        model(x.to(U.DEV), img.to(U.DEV), t=t, validation=True)
+    model.on_range_error = "layers"
+    first = model(x.to(U.DEV), img.to(U.DEV), t=t, validation=True)["diffusion_out"].cpu()
+    assert (first - ref).abs().max().item() < 1e-4               # the fp32 re-run itself is finite and right
+    assert blk + ".attention" in model.f32_layers, sorted(model.f32_layers)
+    model.on_range_error = "raise"
+    mixed = model(x.to(U.DEV), img.to(U.DEV), t=t, validation=True)["diffusion_out"].cpu()
+    err = (mixed - ref).abs().max().item()
+    parity_log("attention_operand_overflow_pinned", max_dp=err, layers_pinned=len(model.f32_layers), bar=1e-4)
+    assert err < 1e-4
+    eng = model._engine(x.to(U.DEV), img.to(U.DEV), None)
+    assert blk + ".attention" in eng.op_names and blk + ".norm_qkv_attention" not in eng.op_names
+
+
+def test_unattributable_overflow_switches_the_model_to_fp32_once(U):
+    """An overflow the probe cannot pin to a layer (here: RANGE_MARGIN raised so that nothing qualifies) must not cost an F16X3 run plus
+    an fp32 re-run on every later call: the model switches to the exact-fp32 kernels for good."""
+    model = build_model(250, "cosine", {"s": 0.008}, [(1, 128, 128), (2, 128, 128)], (1, 128, 128), "unet_openai", LIDC_BP,
+                        "datasets.lidc", "confidence", None)
+    sd = _trained_like_state_dict(model.unet.spec, 0)
+    model.unet.load_state_dict(sd, strict=True)
+    model = model.to("cuda:0").eval()
+    model.RANGE_MARGIN = 1e9
+    rng = np.random.default_rng(8)
+    img = torch.from_numpy(rng.uniform(-1, 1, (2, 1, 128, 128)).astype(np.float32)).to(U.DEV)
+    x = O.one_hot_bchw(torch.from_numpy(rng.integers(0, 2, (2, 128, 128))), 2).to(U.DEV)
+    t = torch.full((2,), 60.0)
+    a = model(x, img, t=t, validation=True)["diffusion_out"]
+    assert model.prec == hip.PREC_F32 and not model.f32_layers
+    assert all(k[6] == hip.PREC_F32 for k in model._engines)
+    b = model(x, img, t=t, validation=True)["diffusion_out"]
+    assert torch.equal(a, b)
+
+
+def test_graph_survives_a_new_philox_key_and_new_noise_blocks(U):
+    """The per-run epilogue fields live in a device block (ccdm_post_run): successive sampling calls (a new Philox key each) and the
+    several host-noise blocks of one call replay ONE captured graph per engine instead of destroying and re-capturing it."""
+    import ccdm_stochastic_segmentation_amd.models as M
+    model = build_model(250, "cosine", {"s": 0.008}, [(1, 128, 128), (2, 128, 128)], (1, 128, 128), "unet_openai", LIDC_BP,
+                        "datasets.lidc", "confidence", None)
+    sd = {k: torch.from_numpy(v) for k, v in make_synthetic_state_dict(model.unet.spec, 0).items()}
+    model.unet.load_state_dict(sd, strict=True)
+    model = model.to("cuda:0").eval()
+    assert model.use_graph
+    rng = np.random.default_rng(3)
+    N = 2
+    image = torch.from_numpy(rng.uniform(-1, 1, (N, 1, 128, 128)).astype(np.float32)).to(U.DEV)
+    x = O.one_hot_bchw(torch.from_numpy(rng.integers(0, 2, (N, 128, 128))), 2).to(U.DEV)
+    t = torch.as_tensor(10004)
+    outs = [model(x, image, t=t)["diffusion_out"].clone() for _ in range(3)]
+    eng = model._engine(x, image, None)
+    assert eng.graph_captures() == 1
+    assert (outs[0] - outs[1]).abs().max() > 1e-3 and (outs[1] - outs[2]).abs().max() > 1e-3        # three different streams
+    model.use_graph, model.philox_call = False, 0
+    assert torch.equal(model(x, image, t=t)["diffusion_out"], outs[0])                              # graph replay == eager, call 0
+    # host noise in blocks of one step: every block hands the epilogue another buffer
+    model.use_graph, model.rng = True, "torch_cpu"
+    old = M.HOST_NOISE_BLOCK_BYTES
+    try:
+        torch.manual_seed(11)
+        whole = model(x, image, t=t)["diffusion_out"].clone()
+        M.HOST_NOISE_BLOCK_BYTES = 1
+        torch.manual_seed(11)
+        blocks = model(x, image, t=t)["diffusion_out"].clone()
+    finally:
+        M.HOST_NOISE_BLOCK_BYTES = old
+    assert torch.equal(whole, blocks)
+    assert eng.graph_captures() == 1
 
 
 # ------------------------------------------------------------------------------------------ A14 variants

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(hip.SIGNATURES), declared ^ set(hip.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ccdm_version() == hip.ABI_VERSION == 6
+    assert lib.ccdm_version() == hip.ABI_VERSION == 7
     assert ctypes.sizeof(hip.ConvArgs) % 8 == 0 and ctypes.sizeof(hip.PostArgs) % 8 == 0
 
 

@@ -54,7 +54,8 @@ def main():
     for t in t_list:
         x = torch.nn.functional.one_hot(torch.from_numpy(rng.integers(0, K, (n, H, W))), K).permute(0, 3, 1, 2).float().to(dev)
         model(x, image, feat, t=torch.full((n,), float(t)), validation=True)
-    probe, model._range_probe = model._range_probe, None
+    probe = model._collect_probe()
+    model._range_probe = None
     rows = sorted(({"layer": k, "max_staged_abs": v, "headroom": (hip.F16X3_LIMIT / v if v > 0 else float("inf"))} for k, v in probe.items()),
                   key=lambda r: r["headroom"])
     limit = hip.F16X3_LIMIT * model.RANGE_MARGIN
