@@ -1111,6 +1111,18 @@ static size_t packed_frag_bytes(int Cout, int Cin, int ksize, int prec) {
     return taps * (cin_pad / 16) * ntiles * 2 * 64 * 16;
 }
 
+// does this conv run the K-split few-pixel kernel?  (a function of the layer's shape and operands only — the host sizes the
+// statistics buffer by it through ccdm_conv_out_slices)
+static bool conv_takes_ks(const ccdm_conv_args& a) {
+    return a.up != 2 && !a.fine_slices && !exp_env("CCDM_NO_KS") && conv_ks_eligible(a);
+}
+
+int conv_out_slices(const ccdm_conv_args& a) {
+    if (a.up == 2) return (conv_geo(a.Hin, a.Win, 1, true).TW == 16 ? 1 : 4) * conv_slices(a.Hin, a.Win, 1, true, a.fine_slices);
+    if (conv_takes_ks(a)) return conv_ks_slices(a);
+    return conv_slices(a.Hout, a.Wout, a.stride, false, a.fine_slices);
+}
+
 int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
     const int C = a.C0 + a.C1;
     CCDM_REQUIRE(a.in0 && a.out && a.w, "conv: null in0/out/w");
@@ -1173,6 +1185,9 @@ int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
     k.tiles_x = cdiv(tW, g.TW);
     k.tiles_y = cdiv(tH, g.TH);
     k.slices = conv_slices(tH, tW, a.stride, up2, a.fine_slices);
+    // few-pixel images: K split over the waves, weight fragments straight from L2 (ccdm_conv_ks.hip) — one statistics slice per 8x8 tile
+    const bool ks = conv_takes_ks(a);
+    if (ks) k.slices = conv_ks_slices(a);
     k.wscale = reinterpret_cast<const float*>(static_cast<const char*>(a.w) +
                                               (up2 ? packed_frag_bytes(4 * a.Cout, C, 2, prec) : packed_frag_bytes(a.Cout, C, a.ksize, prec)));
     const int want_slices = (up2 && NI == 1 ? 4 : 1) * k.slices;      // one phase per block: every (slice, phase) pair leaves a partial
@@ -1183,8 +1198,8 @@ int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
         CCDM_CHECK_LAUNCH("conv1x1");
         return 0;
     }
-    if (!up2 && !a.fine_slices && !exp_env("CCDM_NO_KS") && conv_ks_eligible(a, k.slices)) {   // few-pixel images: K split over the waves, weight fragments straight from L2
-        const int rck = launch_conv_ks(a, k.slices, k.ntiles, k.wscale, s);
+    if (ks) {
+        const int rck = launch_conv_ks(a, k.ntiles, k.wscale, s);
         if (rck) return rck;
         CCDM_CHECK_LAUNCH("conv_ks");
         return 0;
@@ -1250,6 +1265,11 @@ extern "C" int ccdm_upconv_supported(int Cin, int Cout, int prec) {
 
 extern "C" int ccdm_upconv_slices(int Hin, int Win) {
     return (ccdm::conv_geo(Hin, Win, 1, true).TW == 16 ? 1 : 4) * ccdm::conv_slices(Hin, Win, 1, true);
+}
+
+extern "C" int ccdm_conv_out_slices(const ccdm_conv_args* a) {
+    if (!a) return ccdm::fail("ccdm_conv_out_slices: null args");
+    return ccdm::conv_out_slices(*a);
 }
 
 extern "C" int ccdm_conv_slices_ex(int Hin, int Win, int ksize, int stride, int up, int fine) {

@@ -61,8 +61,9 @@ bool conv1x1_eligible(const ccdm_conv_args& a, int slices);
 int launch_conv1x1(const ccdm_conv_args& a, int slices, int ntiles, const float* wscale, hipStream_t s);
 
 // 3x3 conv of a few-pixel image, K split over the waves of a block, weight fragments straight from L2 (ccdm_conv_ks.hip)
-bool conv_ks_eligible(const ccdm_conv_args& a, int slices);
-int launch_conv_ks(const ccdm_conv_args& a, int slices, int ntiles, const float* wscale, hipStream_t s);
+bool conv_ks_eligible(const ccdm_conv_args& a);
+int conv_ks_slices(const ccdm_conv_args& a);            // statistics slices that kernel leaves (one per 8x8 tile)
+int launch_conv_ks(const ccdm_conv_args& a, int ntiles, const float* wscale, hipStream_t s);
 #ifdef CCDM_ABLATION
 bool conv_ks_timeline_read(unsigned long long* host, int n);
 #endif

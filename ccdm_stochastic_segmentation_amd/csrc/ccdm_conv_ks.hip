@@ -18,6 +18,14 @@
 //   epilogue: the 8 partial accumulators meet in LDS (aliasing the dead A tile), wave w adds them in fixed order for output row w of
 //            the tile, adds bias (+emb) (+residual), stores, and leaves the tile's statistics partial — no atomics, fixed order.
 // Same products as the general kernel (lo*hi, hi*lo, hi*hi per k-step), another summation order over K: results agree to fp32 rounding.
+//
+// Round 4 — NI output-channel tiles per block (16x16 images: LIDC's second-deepest stage, 21 launches per denoise step).  There a
+// launch of the general kernel is ONE round of 1.5 blocks per CU and its time is one block's chain — per 32-channel chunk a commit
+// (3 900 cycles), two barriers and a matrix phase (2 950), with the same halo tile normalised, activated and split by each of the
+// three n-tile blocks of a pixel tile (tools/timeline_op.py: 96 -> 96 35 800 cycles, 224 -> 96 74 800).  With all n-tiles of an
+// 8x8 pixel tile in ONE block the grid is 64 samples x 4 tiles = 256 blocks = one per CU: the tile is staged once, every weight
+// fragment of the layer is read by exactly one wave of the block, a step feeds 2 x NI accumulators (6 NI matrix instructions per
+// A / B fragment set), and the partial accumulators meet in LDS one n-tile at a time (the exchange buffer holds one).
 #include "ccdm_common.h"
 #include "ccdm_conv_common.h"
 
@@ -47,14 +55,17 @@ static bool g_ks_stamped = false;
 #define KS_STAMP(slot) do { } while (0)
 #endif
 
-constexpr int KS_NT = 512, KS_NW = 8, KS_BQ = 10, KS_PART_BYTES = 8 * 2 * 4 * 64 * 16;
+constexpr int KS_NT = 512, KS_NW = 8, KS_PART_BYTES = 8 * 2 * 4 * 64 * 16;
+// weight-fragment sets in flight per wave (one set = NI hi|lo pairs = 8 NI registers): ~80-96 registers of queue whatever NI
+constexpr int ks_bq(int ni) { return ni == 1 ? 10 : (ni == 2 ? 6 : (ni == 3 ? 4 : 2)); }
 
 // GNACT: the input is GroupNorm'ed and SiLU'ed on load (ResBlock convs) / staged raw (Downsample) — the only two combinations this
 // kernel is built for.  NITM / NITS: staging items per thread of the halo tile / the skip pixels the instantiation has registers for.
-template <int STRIDE, bool GNACT, int NITM, int NITS>
-__global__ __launch_bounds__(KS_NT, 2) void k_conv_ks(const ConvKS k) {
+template <int STRIDE, bool GNACT, int NITM, int NITS, int NI = 1>
+__global__ __launch_bounds__(KS_NT, NI == 1 ? 2 : 1) void k_conv_ks(const ConvKS k) {
     constexpr int HWt = 7 * STRIDE + 3, HP = HWt * HWt;
     constexpr int NIT = NITM + NITS;
+    constexpr int KS_BQ = ks_bq(NI);
     warm_kernargs<sizeof(ConvKS)>();
     const ccdm_conv_args& a = k.a;
     extern __shared__ __attribute__((aligned(16))) char smem_ks[];
@@ -72,9 +83,21 @@ __global__ __launch_bounds__(KS_NT, 2) void k_conv_ks(const ConvKS k) {
 #endif
     KS_STAMP(1);
     const int ntile_sp = k.tiles_x * k.tiles_y;
-    const int n = blockIdx.x / ntile_sp, tile = blockIdx.x - n * ntile_sp;
+    // several tiles per sample: block b runs on XCD b % 8 — give each XCD a contiguous range of (sample, tile) pairs so that the tiles
+    // of a sample (shared halo rows, the same statistics partials) meet in one L2 (speed only)
+    int bid = blockIdx.x;
+    if (ntile_sp > 1 && (gridDim.x & 7) == 0) bid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int n = __builtin_amdgcn_readfirstlane(bid / ntile_sp), tile = __builtin_amdgcn_readfirstlane(bid - n * ntile_sp);
     const int ty = tile / k.tiles_x, tx = tile - ty * k.tiles_x;
-    const int nt = blockIdx.y;
+    // the step counter and this sample's table row: SCALAR loads, requested before any vector memory request.  (As vector loads behind
+    // the halo and fragment requests their wait was a vmcnt(0): the whole halo round trip sat in front of the epilogue constants, and
+    // the residual requests behind them cost a second full round trip before the GroupNorm table.)
+    typedef const __attribute__((address_space(4))) int32_t* ks_cptr_t;
+    int step = 0, row0 = 0;
+    if (a.step_ptr) step = *(ks_cptr_t)(a.step_ptr);
+    if (a.emb_row_of_sample) row0 = ((ks_cptr_t)(a.emb_row_of_sample))[n];
+    const int emb_row = row0 + step;
+    const int nt = blockIdx.y * NI;                                                     // first n-tile of this block
     const int oy0 = ty * 8, ox0 = tx * 8;
     const int Hin = a.Hin, Win = a.Win;
 
@@ -96,6 +119,7 @@ __global__ __launch_bounds__(KS_NT, 2) void k_conv_ks(const ConvKS k) {
         g_beta = a.beta[tid];
     }
 
+    KS_STAMP(20);
     // ---- 2. halo requests: item i of wave g covers staged pixels (g + 8 i) * PPW .. + PPW - 1, lane = (pixel within the item, channel quad) ----
     const int lgq_m = k.lgq_m, lgq_s = k.lgq_s;
     const int sub_m = lane >> lgq_m, q_m = lane & ((1 << lgq_m) - 1);
@@ -163,31 +187,49 @@ __global__ __launch_bounds__(KS_NT, 2) void k_conv_ks(const ConvKS k) {
     // The vector-memory front end of a CU takes ~40 B/clk from L2: the 147 KB of fragments a 128-channel block needs are ~3 700 cycles of
     // streaming.  Requested in one burst they stall every wave at issue for that long; so only the first pairs go out here, the rest
     // one pair behind each committed halo item (the front end streams them while the waves do the commit's arithmetic).
-    f32x4 bh[KS_BQ], bl[KS_BQ];
+    f32x4 bh[KS_BQ][NI], bl[KS_BQ][NI];       // (the n-tiles of a step are adjacent 2 KB slabs: hi | lo)
     const unsigned lane16 = (unsigned)lane << 4;
-    constexpr int KS_B0 = 2;
+    constexpr int KS_B0 = NI == 1 ? 2 : 1;
+    auto load_set = [&](const int slot, const int j) {
+        const char* p = frag_ptr(j);
 #pragma unroll
-    for (int jj = 0; jj < KS_B0; ++jj) {
-        const char* p = frag_ptr(jj);
-        bh[jj] = load16_uniform_base(p, lane16);
-        bl[jj] = load16_uniform_base(p, lane16 + 1024u);
-    }
+        for (int ni = 0; ni < NI; ++ni) {
+            bh[slot][ni] = load16_uniform_base(p, lane16 + 2048u * ni);
+            bl[slot][ni] = load16_uniform_base(p, lane16 + 2048u * ni + 1024u);
+        }
+    };
+#pragma unroll
+    for (int jj = 0; jj < KS_B0; ++jj) load_set(jj, jj);
+    KS_STAMP(22);
 
-    // ---- 4. epilogue constants and residual of the output row this wave will finish (row g of the tile), requested early ----
-    const int co = nt * 32 + (lane & 31);
-    const int step = a.step_ptr ? *a.step_ptr : 0;
-    const int emb_row = (a.emb_row_of_sample ? a.emb_row_of_sample[n] : 0) + step;
+    // ---- 4. epilogue constants and residual of the output row this wave will finish (row g of the tile).  One n-tile per block: requested
+    //         here, early.  Several: behind the matrix phase (their 7 NI registers would not fit beside 2 NI accumulators and the fragment
+    //         queue — a spilled load destination is a vmcnt(0) in the middle of the prologue), arriving under the first exchange pass ----
+    const int co = nt * 32 + (lane & 31);                               // channel of n-tile 0; n-tile ni: + 32 ni
     const float* const dummyf = reinterpret_cast<const float*>(a.w);
-    const float raw_bias = *(a.bias ? a.bias + co : dummyf);
-    const float raw_emb = *(a.emb_off >= 0 ? a.emb_table + (size_t)emb_row * a.emb_stride + a.emb_off + co : dummyf);
-    const float wsc = k.wscale[co];
+    float raw_bias[NI], raw_emb[NI], wsc[NI];
     // reducer geometry: wave g finishes tile row g; lane = (half h = lane >> 5: pixels 4h .. 4h + 3 of the row, channel lane & 31)
     const size_t obase = (((size_t)n * a.Hout + (oy0 + g)) * a.Wout + ox0 + 4 * (lane >> 5)) * a.Cout + co;
-    float rs[4] = {0.f, 0.f, 0.f, 0.f};
-    if (a.resid) {
+    float rs[NI][4];
+    auto request_epilogue_operands = [&]() {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) rs[j] = a.resid[obase + (size_t)j * a.Cout];
-    }
+        for (int ni = 0; ni < NI; ++ni) {
+            raw_bias[ni] = *(a.bias ? a.bias + co + 32 * ni : dummyf);
+            raw_emb[ni] = *(a.emb_off >= 0 ? a.emb_table + (size_t)emb_row * a.emb_stride + a.emb_off + co + 32 * ni : dummyf);
+            wsc[ni] = k.wscale[co + 32 * ni];
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rs[ni][j] = 0.f;
+        if (a.resid) {
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rs[ni][j] = a.resid[obase + (size_t)j * a.Cout + 32 * ni];
+        }
+    };
+    if constexpr (NI == 1) request_epilogue_operands();
 
     KS_STAMP(3);
     // ---- 5. GroupNorm (scale, shift) table (the staging region is free until the commit) ----
@@ -239,11 +281,7 @@ __global__ __launch_bounds__(KS_NT, 2) void k_conv_ks(const ConvKS k) {
             *reinterpret_cast<u32x2*>(d + lo_off) = lo;
         };
         auto next_pair = [&](const int jj) {
-            if (jj < KS_BQ) {
-                const char* p = frag_ptr(jj);
-                bh[jj < KS_BQ ? jj : 0] = load16_uniform_base(p, lane16);
-                bl[jj < KS_BQ ? jj : 0] = load16_uniform_base(p, lane16 + 1024u);
-            }
+            if (jj < KS_BQ) load_set(jj < KS_BQ ? jj : 0, jj);
         };
         const int Cm2 = 32 * k.nks_m, Cs2 = 32 * k.nks_s;               // bytes of a pixel's hi plane
         const bool wr_m = 4 * q_m < 16 * k.nks_m, wr_s = 4 * q_s < 16 * k.nks_s;      // lanes beyond the padded channel count write nothing
@@ -264,6 +302,7 @@ __global__ __launch_bounds__(KS_NT, 2) void k_conv_ks(const ConvKS k) {
                 hp += dhp; dm += ddm;
             }
             next_pair(KS_B0 + i);
+            KS_STAMP(30 + i);
         }
         if constexpr (NITS > 0) {
             const int dpx = KS_NW << (6 - lgq_s);
@@ -287,11 +326,13 @@ __global__ __launch_bounds__(KS_NT, 2) void k_conv_ks(const ConvKS k) {
     KS_STAMP(6);
 
     // ---- 7. matrix phase: this wave's steps, both sub-tiles, fragments from registers (B) and LDS (A) ----
-    f32x16 acc[2];
+    f32x16 acc[2][NI];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
     int abase[2], sbase[2];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
@@ -334,71 +375,80 @@ __global__ __launch_bounds__(KS_NT, 2) void k_conv_ks(const ConvKS k) {
                 const int cur = jj & 1;      // (KS_BQ is even: the parity of a step is static after unrolling)
                 frag_load_a(cur ^ 1, j + 1);
                 __builtin_amdgcn_sched_barrier(0);                       // keep the requests in front of the MFMAs
-                const f16x8 wh = __builtin_bit_cast(f16x8, bh[jj]), wl = __builtin_bit_cast(f16x8, bl[jj]);
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][mi], wh, acc[mi], 0, 0, 0);
+                for (int ni = 0; ni < NI; ++ni) {
+                    const f16x8 wh = __builtin_bit_cast(f16x8, bh[jj][ni]), wl = __builtin_bit_cast(f16x8, bl[jj][ni]);
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][mi], wl, acc[mi], 0, 0, 0);
+                    for (int mi = 0; mi < 2; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][mi], wh, acc[mi][ni], 0, 0, 0);
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][mi], wh, acc[mi], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (j + KS_BQ < nsw) {       // the slot's fragments of the next batch (wide inputs)
-                    const char* p = frag_ptr(j + KS_BQ);
-                    bh[jj] = load16_uniform_base(p, lane16);
-                    bl[jj] = load16_uniform_base(p, lane16 + 1024u);
+                    for (int mi = 0; mi < 2; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][mi], wl, acc[mi][ni], 0, 0, 0);
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][mi], wh, acc[mi][ni], 0, 0, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                if (j + KS_BQ < nsw) load_set(jj, j + KS_BQ);       // the slot's fragments of the next batch (wide inputs)
             }
         }
     };
     batch(0);
     for (int j0 = KS_BQ; j0 < nsw; j0 += KS_BQ) batch(j0);
 
-    // ---- 8. cross-wave reduction: partial [wave][sub-tile][row quad][lane] x 16 B, then wave g finishes tile row g ----
+    if constexpr (NI > 1) request_epilogue_operands();
+    // ---- 8. cross-wave reduction, one n-tile at a time: partial [wave][sub-tile][row quad][lane] x 16 B, then wave g finishes tile row g ----
     KS_STAMP(7);
     __syncthreads();                         // every wave is done reading the A tile
     KS_STAMP(8);
-    {
-        f32x4* part = reinterpret_cast<f32x4*>(region);
+    float t1[NI], t2[NI];
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+    for (int ni = 0; ni < NI; ++ni) {
+        if (ni > 0) __syncthreads();         // the previous n-tile's partials have been consumed
+        {
+            f32x4* part = reinterpret_cast<f32x4*>(region);
 #pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                f32x4 v;
-                v[0] = acc[mi][4 * rq]; v[1] = acc[mi][4 * rq + 1]; v[2] = acc[mi][4 * rq + 2]; v[3] = acc[mi][4 * rq + 3];
-                part[((g * 2 + mi) * 4 + rq) * 64 + lane] = v;
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    f32x4 v;
+                    v[0] = acc[mi][ni][4 * rq]; v[1] = acc[mi][ni][4 * rq + 1]; v[2] = acc[mi][ni][4 * rq + 2]; v[3] = acc[mi][ni][4 * rq + 3];
+                    part[((g * 2 + mi) * 4 + rq) * 64 + lane] = v;
+                }
+        }
+        __syncthreads();
+        if (ni == 0) KS_STAMP(9);
+        t1[ni] = 0.f; t2[ni] = 0.f;
+        {
+            // accumulator register 4 rq + j of sub-tile mi holds pixel mi*32 + 8 rq + 4 (lane >> 5) + j, i.e. tile row 4 mi + rq, column 4 (lane >> 5) + j
+            const f32x4* part = reinterpret_cast<const f32x4*>(region) + ((g >> 2) * 4 + (g & 3)) * 64 + lane;
+            f32x4 v = part[0];
+#pragma unroll
+            for (int w = 1; w < KS_NW; ++w) v += part[w * 8 * 64];                            // fixed order: wave 0 + 1 + ... + 7
+            float add = a.bias ? raw_bias[ni] : 0.f;
+            if (a.emb_off >= 0) add += raw_emb[ni];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float o = fmaf(v[j], wsc[ni], add);                                           // wsc is a power of two: exact product
+                if (a.resid) o += rs[ni][j];
+                a.out[obase + (size_t)j * a.Cout + 32 * ni] = o;
+                t1[ni] += o;
+                t2[ni] = fmaf(o, o, t2[ni]);
             }
-    }
-    __syncthreads();
-    KS_STAMP(9);
-    float t1 = 0.f, t2 = 0.f;
-    {
-        // accumulator register 4 rq + j of sub-tile mi holds pixel mi*32 + 8 rq + 4 (lane >> 5) + j, i.e. tile row 4 mi + rq, column 4 (lane >> 5) + j
-        const f32x4* part = reinterpret_cast<const f32x4*>(region) + ((g >> 2) * 4 + (g & 3)) * 64 + lane;
-        f32x4 v = part[0];
-#pragma unroll
-        for (int w = 1; w < KS_NW; ++w) v += part[w * 8 * 64];                            // fixed order: wave 0 + 1 + ... + 7
-        float add = a.bias ? raw_bias : 0.f;
-        if (a.emb_off >= 0) add += raw_emb;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float o = fmaf(v[j], wsc, add);                                               // wsc is a power of two: exact product
-            if (a.resid) o += rs[j];
-            a.out[obase + (size_t)j * a.Cout] = o;
-            t1 += o;
-            t2 = fmaf(o, o, t2);
         }
     }
     KS_STAMP(10);
     if (a.out_stats) {
-        double v1 = (double)t1, v2 = (double)t2;
-        v1 += __shfl_xor(v1, 32);
-        v2 += __shfl_xor(v2, 32);
-        if (lane < 32) { red[(g * 32 + lane) * 2] = v1; red[(g * 32 + lane) * 2 + 1] = v2; }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            double v1 = (double)t1[ni], v2 = (double)t2[ni];
+            v1 += __shfl_xor(v1, 32);
+            v2 += __shfl_xor(v2, 32);
+            if (lane < 32) { red[((ni * KS_NW + g) * 32 + lane) * 2] = v1; red[((ni * KS_NW + g) * 32 + lane) * 2 + 1] = v2; }
+        }
         __syncthreads();
-        if (tid < 32) {
+        if (tid < 32 * NI) {
+            const int ni = tid >> 5, l = tid & 31;
             double s1 = 0.0, s2 = 0.0;
-            for (int w = 0; w < KS_NW; ++w) { s1 += red[(w * 32 + tid) * 2]; s2 += red[(w * 32 + tid) * 2 + 1]; }
-            double* o = a.out_stats + (((size_t)n * ntile_sp + tile) * a.Cout + nt * 32 + tid) * 2;
+            for (int w = 0; w < KS_NW; ++w) { s1 += red[((ni * KS_NW + w) * 32 + l) * 2]; s2 += red[((ni * KS_NW + w) * 32 + l) * 2 + 1]; }
+            double* o = a.out_stats + (((size_t)n * ntile_sp + tile) * a.Cout + (nt + ni) * 32 + l) * 2;
             o[0] = s1; o[1] = s2;
         }
     }
@@ -413,8 +463,19 @@ static int pow2_lg_quads(int nks) {          // lanes per staged pixel: 4 nks ch
     return q <= 16 ? 4 : (q <= 32 ? 5 : 6);
 }
 
+// n-tiles per block: a rule of the image size and the channel count, never of N (the statistics partials follow the tiling).
+//   <= 128 pixels (one or two 8x8 tiles per sample: LIDC's 8x8 stage, 64 blocks per n-tile at batch 64): 1 — the n-tiles are the grid
+//   <= 256 pixels (16x16: 4 tiles per sample, 256 pixel tiles at batch 64 = one per CU): every n-tile of the layer, at most 4
+static int conv_ks_ni(const ccdm_conv_args& a) {
+    if (a.Hout * a.Wout <= 128) return 1;
+    const int nt = a.Cout / 32;
+    for (int ni = 4; ni > 1; --ni)
+        if (nt % ni == 0) return ni;
+    return 1;
+}
+
 // geometry and resources of a launch; false = not for this kernel
-static bool conv_ks_plan(const ccdm_conv_args& a, int slices, ConvKS& k, size_t& lds, int& nit_max) {
+static bool conv_ks_plan(const ccdm_conv_args& a, ConvKS& k, size_t& lds, int& nit_max, int& NI) {
 #ifdef CCDM_ABLATION
     if ((a.prec & ~(16 << 8)) != CCDM_PREC_F16X3) return false;           // (the timeline bit is this kernel's too)
 #else
@@ -422,12 +483,14 @@ static bool conv_ks_plan(const ccdm_conv_args& a, int slices, ConvKS& k, size_t&
 #endif
     if (a.ksize != 3 || a.up || a.film || (a.stride != 1 && a.stride != 2)) return false;
     if ((a.stats0 != nullptr) != (a.act == CCDM_ACT_SILU)) return false;  // built for GroupNorm + SiLU on load, or neither
-    if (a.Hout % 8 || a.Wout % 8 || a.Hout * a.Wout > 128) return false;   // the images conv_geo() tiles 8x8: a rule of the geometry, never of N
+    const int max_area = exp_env("CCDM_KS_MAX_AREA") ? exp_env("CCDM_KS_MAX_AREA") : 256;      // (A/B hook of experiments builds: 128 = round 3)
+    if (a.Hout % 8 || a.Wout % 8 || a.Hout * a.Wout > max_area) return false;   // a rule of the geometry, never of N
     if (a.Cout % 32) return false;
     const int C = a.C0 + a.C1, SC = a.skip0 ? a.SC0 + a.SC1 : 0;
     if (C > 256 || SC > 256 || (a.stride == 2 && a.skip0)) return false;
-    const int tiles = (a.Hout / 8) * (a.Wout / 8);
-    if (a.out_stats && slices != tiles) return false;
+    NI = conv_ks_ni(a);
+    // instantiations with several n-tiles per block: the ResBlock convs (GroupNorm + SiLU on load, stride 1) and Downsample (raw, stride 2)
+    if (NI > 1 && ((a.stride == 1) != (a.stats0 != nullptr))) return false;
     k.a = a;
     k.C = C; k.SC = SC;
     k.nks_m = cdiv(C, 16); k.nks_s = cdiv(SC, 16);
@@ -448,28 +511,47 @@ static bool conv_ks_plan(const ccdm_conv_args& a, int slices, ConvKS& k, size_t&
     const size_t ex = (size_t)(C > KS_NT ? C : KS_NT) * 16;               // gn_affine_block's exchange
     if (a.stats0 && stage < ex) stage = ex;
     k.red_off = (int)stage;
-    lds = (a.stats0 ? (size_t)C * 8 : 0) + stage + (size_t)KS_NW * 32 * 16;
+    lds = (a.stats0 ? (size_t)C * 8 : 0) + stage + (size_t)NI * KS_NW * 32 * 16;
     return lds <= 160 * 1024;
 }
 
-bool conv_ks_eligible(const ccdm_conv_args& a, int slices) {
+bool conv_ks_eligible(const ccdm_conv_args& a) {
     ConvKS k;
     size_t lds;
-    int nit;
-    return conv_ks_plan(a, slices, k, lds, nit);
+    int nit, ni;
+    return conv_ks_plan(a, k, lds, nit, ni);
 }
 
-int launch_conv_ks(const ccdm_conv_args& a, int slices, int ntiles, const float* wscale, hipStream_t s) {
+// statistics slices a launch of this kernel leaves: one per 8x8 tile
+int conv_ks_slices(const ccdm_conv_args& a) { return (a.Hout / 8) * (a.Wout / 8); }
+
+template <int NI>
+static void launch_conv_ks_ni(const ConvKS& k, dim3 grid, dim3 block, size_t lds, hipStream_t s) {
+    const ccdm_conv_args& a = k.a;
+    const bool gnact = a.stats0 != nullptr;
+    if (a.stride == 1) {
+        if (a.skip0) hipLaunchKernelGGL((k_conv_ks<1, true, 8, 8, NI>), grid, block, lds, s, k);
+        else hipLaunchKernelGGL((k_conv_ks<1, true, 13, 0, NI>), grid, block, lds, s, k);
+    } else {
+        hipLaunchKernelGGL((k_conv_ks<2, false, 20, 0, NI>), grid, block, lds, s, k);
+    }
+    (void)gnact;
+}
+
+int launch_conv_ks(const ccdm_conv_args& a, int ntiles, const float* wscale, hipStream_t s) {
     ConvKS k;
     size_t lds;
-    int nit;
-    if (!conv_ks_plan(a, slices, k, lds, nit)) return fail("conv_ks: geometry not built");
+    int nit, NI;
+    if (!conv_ks_plan(a, k, lds, nit, NI)) return fail("conv_ks: geometry not built");
     k.wscale = wscale;
     k.ntiles = ntiles;
-    const dim3 grid(a.N * k.tiles_x * k.tiles_y, a.Cout / 32), block(KS_NT);
+    const dim3 grid(a.N * k.tiles_x * k.tiles_y, a.Cout / (32 * NI)), block(KS_NT);
 #ifdef CCDM_ABLATION
     if ((a.prec >> 8) & 16) g_ks_stamped = true;
 #endif
+    if (NI == 4) { launch_conv_ks_ni<4>(k, grid, block, lds, s); return 0; }
+    if (NI == 3) { launch_conv_ks_ni<3>(k, grid, block, lds, s); return 0; }
+    if (NI == 2) { launch_conv_ks_ni<2>(k, grid, block, lds, s); return 0; }
     const bool gnact = a.stats0 != nullptr;
     if (a.stride == 1) {
         if (a.skip0) {

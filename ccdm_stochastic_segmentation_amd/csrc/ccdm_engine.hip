@@ -66,6 +66,7 @@ struct ccdm_engine {
     hipGraphExec_t exec = nullptr;
     bool graph_valid = false;
     int graph_with_epilogue = -1;
+    int exp_id = 0;              // creation index (experiments builds: per-stream op skipping)
     int captures = 0;            // how often the step has been captured and instantiated (tests: a new Philox key must not re-capture)
     // timing taps: HIP events around every launch of the tapped ops (op index -> events, launches recorded)
     struct Tap { std::vector<hipEvent_t> ev; int n = 0; };
@@ -82,24 +83,32 @@ static void drop_graph(ccdm_engine* e) {
 
 #ifdef CCDM_EXPERIMENTS
 // sensitivity probe (experiments builds only; results are garbage): CCDM_SKIP_OPS="a-b,c,d-e" leaves those ops of the step out, to see
-// how much of the step time — in whatever launch mode — a stage is worth before anyone rewrites its kernels
-static bool exp_skip_op(size_t i) {
-    static std::vector<std::pair<int, int>> ranges;
+// how much of the step time — in whatever launch mode — a stage is worth before anyone rewrites its kernels.  CCDM_SKIP_OPS_B, when
+// set, is the list for every second engine created (the second of two sub-batch streams): one stream can run only the
+// full-resolution ops and the other only the low-resolution ones.
+static int g_exp_engines = 0;
+static bool exp_skip_op(int engine_id, size_t i) {
+    static std::vector<std::pair<int, int>> ranges[2];
     static bool parsed = false;
     if (!parsed) {
         parsed = true;
-        const char* v = getenv("CCDM_SKIP_OPS");
-        while (v && *v) {
-            char* end;
-            const int a = (int)strtol(v, &end, 10);
-            int b = a;
-            if (*end == '-') b = (int)strtol(end + 1, &end, 10);
-            ranges.push_back({a, b});
-            v = *end == ',' ? end + 1 : end;
-            if (end == v && *v) break;
+        const char* va = getenv("CCDM_SKIP_OPS");
+        const char* vb = getenv("CCDM_SKIP_OPS_B");
+        const char* vs[2] = {va, vb ? vb : va};
+        for (int q = 0; q < 2; ++q) {
+            const char* v = vs[q];
+            while (v && *v) {
+                char* end;
+                const int a = (int)strtol(v, &end, 10);
+                int b = a;
+                if (*end == '-') b = (int)strtol(end + 1, &end, 10);
+                ranges[q].push_back({a, b});
+                if (end == v) break;
+                v = *end == ',' ? end + 1 : end;
+            }
         }
     }
-    for (auto& r : ranges) if ((int)i >= r.first && (int)i <= r.second) return true;
+    for (auto& r : ranges[engine_id & 1]) if ((int)i >= r.first && (int)i <= r.second) return true;
     return false;
 }
 #endif
@@ -108,7 +117,7 @@ static int launch_step(ccdm_engine* e, int with_epilogue, hipStream_t s, bool pr
     for (size_t i = 0; i < e->ops.size(); ++i) {
         const Op& op = e->ops[i];
 #ifdef CCDM_EXPERIMENTS
-        if (exp_skip_op(i)) continue;
+        if (exp_skip_op(e->exp_id, i)) continue;
 #endif
         ccdm_engine::Tap* tp = nullptr;
         if (profile) {
@@ -133,6 +142,9 @@ extern "C" ccdm_engine* ccdm_engine_create(int32_t* step_counter) {
     if (!step_counter) { fail("engine_create: null step counter"); return nullptr; }
     ccdm_engine* e = new ccdm_engine();
     e->step = step_counter;
+#ifdef CCDM_EXPERIMENTS
+    e->exp_id = g_exp_engines++;
+#endif
     return e;
 }
 

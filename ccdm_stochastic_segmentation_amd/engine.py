@@ -152,7 +152,6 @@ class SamplerEngine:
         hout = (hc + 2 * pad - ksize) // stride + 1
         wout = (wc + 2 * pad - ksize) // stride + 1
         up_mode = 2 if subpixel else int(bool(up))
-        out = self._act(cout, hout, wout, stats, self.lib.ccdm_conv_slices_ex(hin, win, ksize, stride, up_mode, int(self.fine_slices)))
         args = hip.ConvArgs()
         args.in0, args.C0 = a.ptr, a.C
         args.in1, args.C1 = (b.ptr, b.C) if b else (0, 0)
@@ -173,14 +172,16 @@ class SamplerEngine:
         args.resid = resid.ptr if resid is not None else 0
         if resid is not None:
             assert (resid.C, resid.h, resid.w) == (cout, hout, wout), wkey
-        args.out = out.ptr
-        args.out_stats, args.out_slices = out.stats_ptr, out.slices
         if skip_src is not None:
             sa, sb = skip_src[0], (skip_src[1] if len(skip_src) > 1 else None)
             assert (sa.h, sa.w) == (hout, wout), wkey
             args.skip0, args.SC0 = sa.ptr, sa.C
             args.skip1, args.SC1 = (sb.ptr, sb.C) if sb else (0, 0)
             args.skip_w = skip_w.data_ptr()
+        # the statistics slices this launch will leave: the library's answer for the fully described layer (the kernel it selects owns the tiling)
+        out = self._act(cout, hout, wout, stats, hip.check(self.lib.ccdm_conv_out_slices(C.byref(args)), "conv_out_slices " + wkey))
+        args.out = out.ptr
+        args.out_stats, args.out_slices = out.stats_ptr, out.slices
         if len(self.op_names) == _TIMELINE_OP:      # diagnostics: phase stamps of one block of this op (-DCCDM_ABLATION library only)
             args.prec |= 16 << 8
         hip.check(self.lib.ccdm_engine_add_conv(self._handle, C.byref(args)), "engine_add_conv " + wkey)

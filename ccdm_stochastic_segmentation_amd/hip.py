@@ -109,6 +109,7 @@ SIGNATURES = {
     "ccdm_gn_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "ccdm_conv_slices": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "ccdm_conv_slices_ex": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ccdm_conv_out_slices": (C.c_int, [C.POINTER(ConvArgs)]),
     "ccdm_upconv_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "ccdm_upconv_slices": (C.c_int, [C.c_int, C.c_int]),
     "ccdm_pack_upconv_weight": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -104,6 +104,10 @@ typedef struct ccdm_conv_args {
 int ccdm_conv_slices(int Hout, int Wout, int stride, int ksize);
 /* out_slices of any conv: geometry of the INPUT, `up` as in ccdm_conv_args (2: sub-pixel form), fine as ccdm_conv_args.fine_slices */
 int ccdm_conv_slices_ex(int Hin, int Win, int ksize, int stride, int up, int fine);
+/* out_slices of THIS conv (every field but out / out_stats / out_slices filled in): the rule above, except where the layer runs a
+ * kernel with its own tiling — 3x3 F16X3 convs of images of at most 256 pixels leave one slice per 8x8 tile (16x16: 4, where the
+ * rule says 2).  A function of the layer's shape and operands, never of N.  What a caller should size out_stats by. */
+int ccdm_conv_out_slices(const ccdm_conv_args* a);
 /* Upsample (nearest x2) + conv 3x3 in sub-pixel form (unet.py:106-116), `up = 2`:
  *   out(2y+dy, 2x+dx) = sum over a,b in {0,1} of W'[dy,dx][a,b] . in(y+dy-1+a, x+dx-1+b),
  *   W'[dy][..][a] = the 3x3 kernel rows that land on low-resolution row y+dy-1+a  (dy=0: {r0}, {r1+r2}; dy=1: {r0+r1}, {r2}; columns alike):

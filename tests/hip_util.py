@@ -96,9 +96,9 @@ def conv2d(srcs, weight, bias, ksize, *, stats=None, gamma=None, beta=None, act=
     args.out = out.data_ptr()
     ost = None
     if want_stats:
-        S = lib.ccdm_conv_slices_ex(Hin, Win, ksize, stride, int(up), int(fine))
-        if not fine:
-            assert S == (lib.ccdm_upconv_slices(Hin, Win) if up == 2 else lib.ccdm_conv_slices(Hout, Wout, stride, ksize))
+        S = hip.check(lib.ccdm_conv_out_slices(C.byref(args)), "conv_out_slices")     # the kernel the library selects owns the tiling
+        if up == 2 and not fine:
+            assert S == lib.ccdm_upconv_slices(Hin, Win)
         ost = torch.empty((N, S, cout, 2), dtype=torch.float64, device=DEV)
         args.out_stats, args.out_slices = ost.data_ptr(), S
     hip.check(lib.ccdm_conv2d(C.byref(args), 0), "conv2d")

@@ -295,6 +295,16 @@ CONV_KS_CASES = [
     (48, 16, 32, 8, 8, 3, 1, 0, 0, 1, 0, 0),       # SiLU without GroupNorm, seam inside a 16-channel k-step
     (20, 0, 32, 8, 8, 3, 1, 0, 0, 0, 0, 1),        # 20 channels padded to 32: the padded quads must be staged as zeros
     (160, 0, 96, 8, 8, 3, 1, 0, 1, 1, 0, 0),       # 160 channels: 40 of 64 lanes per pixel
+    # 16x16 outputs (129..256 pixels): every n-tile of the layer in one block (NI = Cout / 32 up to 4), one block per 8x8 tile
+    (96, 0, 96, 16, 16, 3, 1, 0, 1, 1, 1, 0),      # ResBlock.in_layers at LIDC's 16x16 stage: three n-tiles per block
+    (96, 0, 96, 16, 16, 3, 1, 0, 1, 1, 0, 1),      # out_layers + identity residual
+    (128, 96, 96, 16, 16, 3, 1, 0, 1, 1, 1, 0),    # decoder in_layers: 224 channels over the concat seam (13 halo items per thread)
+    (64, 0, 96, 16, 16, 3, 1, 0, 1, 1, 1, 0),      # 64 -> 96
+    (64, 0, 64, 32, 32, 3, 2, 0, 0, 0, 0, 0),      # Downsample 32x32 -> 16x16: two n-tiles per block, stride-2 halo
+    (96, 0, 128, 16, 16, 3, 1, 0, 1, 1, 0, 1),     # four n-tiles per block
+    (32, 0, 160, 16, 16, 3, 1, 0, 1, 1, 1, 1),     # five n-tiles: no divisor <= 4 besides 1 -> one n-tile per block, grid.y = 5
+    (64, 0, 64, 8, 32, 3, 1, 0, 1, 1, 1, 0),       # 8x32: four tiles in a row
+    (64, 0, 64, 16, 16, 3, 1, 0, 0, 1, 0, 0),      # SiLU without GroupNorm at NI > 1: not built there -> the general kernel and its slices
 ]
 
 
@@ -332,7 +342,7 @@ def test_conv_few_pixel_kernel(U, case):
 
 
 @pytest.mark.parametrize("c0,c1,cout,H,W", [(256, 0, 128, 8, 8), (128, 96, 128, 8, 8), (128, 128, 128, 8, 16), (64, 32, 64, 16, 8), (32, 0, 64, 8, 8),
-                                             (160, 0, 96, 8, 8)])
+                                             (160, 0, 96, 8, 8), (128, 96, 96, 16, 16), (96, 96, 96, 16, 16), (96, 64, 96, 16, 16), (64, 64, 128, 16, 16)])
 def test_conv_few_pixel_kernel_fused_skip(U, c0, c1, cout, H, W):
     """decoder ResBlock tail at the deepest levels: the fused 1x1 skip segment as extra K steps of ccdm_conv_ks.hip (raw input, 64 core
     pixels staged behind the halo tile)"""

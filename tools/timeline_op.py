@@ -33,8 +33,9 @@ if __name__ == "__main__":
         prev = t
     if os.environ.get("CCDM_TIMELINE_KS"):      # ccdm_conv_ks.hip's stamps
         NAMES.clear()
-        NAMES.update({1: "entry", 2: "halo-issued", 3: "B+epi-issued", 4: "gn-table", 5: "commit", 6: "barrier", 7: "mfma", 8: "barrier", 9: "partials+barrier",
-                      10: "reduce+store", 11: "stats"})
+        NAMES.update({1: "entry", 2: "halo-issued", 3: "resid-issued", 4: "gn-table", 5: "commit", 6: "barrier", 7: "mfma", 8: "barrier", 9: "partials+barrier",
+                      10: "reduce+store", 11: "stats", 20: "gn-requested", 22: "B0-issued", 23: "epi-consts-issued"})
+        NAMES.update({30 + i: f"item{i}" for i in range(24)})
         out = []
         prev = ev[0][1]
         for slot, t in ev[1:]:
