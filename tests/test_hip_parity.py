@@ -1888,6 +1888,57 @@ def test_two_ranks_of_the_real_model_reproduce_the_single_process_run(U, tmp_pat
     assert res and all(res.values()), res
 
 
+RCCL_WORKER = r"""
+import os, sys, json
+sys.path.insert(0, os.environ["CCDM_ROOT"])
+import torch
+import torch.distributed as dist
+from ccdm_stochastic_segmentation_amd.distributed import all_gather_shards, sample_sharded
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", rank=0, world_size=1)        # "nccl" is RCCL on ROCm
+dev = torch.device("cuda", 0)
+ok = {}
+dist.barrier()
+x = torch.arange(2 * 3 * 8 * 8, dtype=torch.float32, device=dev).reshape(2, 3, 8, 8)
+full, buf = all_gather_shards(x, 2, 1)
+ok["all_gather_into_tensor"] = bool(torch.equal(full, x))
+full2, buf2 = all_gather_shards(x + 1, 2, 1, buf)
+ok["buffer_reused"] = bool(buf2.data_ptr() == buf.data_ptr() and torch.equal(full2, x + 1))
+mine = torch.tensor([1.5, 0.25], device=dev, dtype=torch.float64)
+allr = [torch.empty_like(mine)]
+dist.all_gather(allr, mine)                                            # bench.py's per-rank timing exchange
+ok["all_gather_list"] = bool(torch.equal(allr[0], mine))
+idx = torch.randint(0, 20, (2, 8, 8), device=dev).to(torch.uint8)
+g, _ = all_gather_shards(idx, 2, 1)
+ok["uint8_index_gather"] = bool(torch.equal(g, idx))
+dist.barrier()
+torch.cuda.synchronize()
+dist.destroy_process_group()
+print("RESULT " + json.dumps(ok))
+"""
+
+
+def test_rccl_single_rank_collectives(U, tmp_path):
+    """RCCL itself (torch.distributed backend "nccl") on this box: a one-rank process group runs exactly the collectives the N > 1 path
+    of bench.py / sample_sharded issues — barrier, all_gather_into_tensor into a reused buffer (fp32 and uint8 index form), the
+    list-form all_gather of the per-rank timings.  (Two ranks cannot share one GPU under RCCL; the two-rank logic runs under gloo
+    above.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER)
+    env = dict(os.environ, CCDM_ROOT=root, MASTER_ADDR="127.0.0.1", MASTER_PORT="29655", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+    res = json.loads(line[len("RESULT "):])
+    assert res and all(res.values()), res
+
+
 # ------------------------------------------------------------------------------------------ N2 harness vs the reference's Tester
 @pytest.mark.parametrize("vote", ["confidence", "majority"])
 def test_lidc_harness_numbers_match_reference_tester(U, golden, vote):
