@@ -144,6 +144,28 @@ def self_launch(args) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def offline_pmc_traffic(config: str, grid_threads: int):
+    """HBM bytes per launch of the dominant kernel class from the newest committed PMC summary of this config (profiles/r*_pmc_bench_<cfg>.json:
+    rocprofv3 --pmc passes over this same bench command in its single-stream eager form, tools/pmc_bench.sh — FETCH_SIZE / WRITE_SIZE in
+    separate passes, corrected as MI355X_MICROARCH.md prescribes).  Counters cannot be read inside a timed run, so the figure is the
+    off-line one for the same (kernel symbol, grid); None when no summary matches."""
+    import glob
+    import re
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    files = sorted(glob.glob(os.path.join(root, f"r*_pmc_bench_{config}.json")), key=lambda f: int(re.search(r"r(\d+)_", os.path.basename(f)).group(1)))
+    for f in reversed(files):
+        try:
+            ks = json.load(open(f)).get("kernels", {})
+        except Exception:
+            continue
+        for key, e in ks.items():
+            if "k_conv<1, 16, 3, 1, 8, 32, 4, 2, 1, 1, false, false>" in key and f"grid={grid_threads} " in key and "hbm_bytes" in e:
+                return e["hbm_bytes"], (f"off-line PMC passes over this bench command (single-stream eager form), {os.path.basename(f)}: FETCH_SIZE x 2 (gfx950 wide-read "
+                                        f"correction) + WRITE_SIZE, KiB -> bytes, mean over {e.get('launches')} launches of this (kernel, grid); measured on another visit, "
+                                        "not in this run")
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -333,9 +355,11 @@ def main():
                 sh["bytes_io"] += o["io_bytes"] * n + o["weight_bytes"]
                 sh["flop"] += o["flop"] * n
                 sh["ops"].append(i)
+            traffic, traffic_src = offline_pmc_traffic(args.config, n * hip.load().ccdm_conv_slices(H, W, 1, 3) * 256) if f16 else (None, None)
             res["roofline"] = {
                 "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                "traffic": None, "traffic_source": "PMC passes are collected off-line (profiles/): HBM counters cannot be read inside the bench run",
+                "traffic": traffic,
+                "traffic_source": traffic_src or "PMC passes are collected off-line (profiles/): HBM counters cannot be read inside the bench run",
                 "note": tap_note,
                 "kernel": f"ccdm::k_conv<F16X3,16,3,1,8,32,4,2,1,1> (<PREC,CK,KS,STRIDE,TH,TW,WAVES,MI,NI,KSP>): every 3x3 stride-1 conv of the {H}x{W} stage "
                           f"(engine ops {dom_ops}), GN+SiLU on load" if f16 else f"ccdm::k_conv<F32,...> every 3x3 stride-1 conv of the {H}x{W} stage (engine ops {dom_ops})",

@@ -26,13 +26,20 @@ __device__ __forceinline__ f32x4 load16_global(const char* p) {
 }
 
 // NT: non-temporal (streaming) store — the line is marked evict-first in L2
+// CCDM_SC1_STORES (build-time probe): write-through stores (sc1: the line leaves the XCD's L2 at once) — what a kernel leaves dirty in
+// L2 is written back at the kernel boundary, B / 6 TB/s on the critical path of the next launch (MI355X_MICROARCH.md, "boundary")
 template <bool NT = false>
 __device__ __forceinline__ void store16_uniform_base(char* base, unsigned voff, const f32x4 v) {
     const unsigned long long u = reinterpret_cast<unsigned long long>(base);
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+#ifdef CCDM_SC1_STORES
+    const unsigned long long sb = ((unsigned long long)hi << 32) | lo;
+    asm volatile("global_store_dwordx4 %0, %1, %2 sc1" : : "v"(voff), "v"(v), "s"(sb) : "memory");
+#else
     __attribute__((address_space(1))) char* g = reinterpret_cast<__attribute__((address_space(1))) char*>(((unsigned long long)hi << 32) | lo);
     if (NT) __builtin_nontemporal_store(v, reinterpret_cast<__attribute__((address_space(1))) f32x4*>(g + voff));
     else *reinterpret_cast<__attribute__((address_space(1))) f32x4*>(g + voff) = v;
+#endif
 }
 // fp16 hi/lo split of two fp32 values: hi = RNE(x) packed, lo = RNE(x - hi) packed.  x - hi is one v_fma_mix_f32 (the fp16 half is
 // read straight out of the packed register and widened by the instruction: fma(hi, -1, x), exactly the subtraction's single rounding),

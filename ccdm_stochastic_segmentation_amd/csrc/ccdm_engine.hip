@@ -66,6 +66,7 @@ struct ccdm_engine {
     hipGraphExec_t exec = nullptr;
     bool graph_valid = false;
     int graph_with_epilogue = -1;
+    int graph_steps = 1;         // denoise steps per captured graph
     int exp_id = 0;              // creation index (experiments builds: per-stream op skipping)
     int captures = 0;            // how often the step has been captured and instantiated (tests: a new Philox key must not re-capture)
     // timing taps: HIP events around every launch of the tapped ops (op index -> events, launches recorded)
@@ -277,7 +278,12 @@ extern "C" int ccdm_engine_run(ccdm_engine* e, int first_row, int n_steps, int w
             drop_graph(e);
             hipError_t err = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed);
             if (err != hipSuccess) return fail("engine_run: BeginCapture: %s", hipGetErrorString(err));
-            int rc = launch_step(e, with_epilogue, s, false);
+            int rc = 0;
+            e->graph_steps = 1;
+#ifdef CCDM_EXPERIMENTS
+            if (exp_env("CCDM_GRAPH_STEPS") > 1) e->graph_steps = exp_env("CCDM_GRAPH_STEPS");      // probe: several denoise steps per captured graph
+#endif
+            for (int g = 0; g < e->graph_steps && !rc; ++g) rc = launch_step(e, with_epilogue, s, false);
             err = hipStreamEndCapture(s, &e->graph);
             if (rc) { if (e->graph) { (void)hipGraphDestroy(e->graph); e->graph = nullptr; } return rc; }
             if (err != hipSuccess) return fail("engine_run: EndCapture: %s", hipGetErrorString(err));
@@ -287,9 +293,14 @@ extern "C" int ccdm_engine_run(ccdm_engine* e, int first_row, int n_steps, int w
             e->graph_with_epilogue = with_epilogue;
             e->captures++;
         }
-        for (int i = 0; i < n_steps; ++i) {
+        int i = 0;
+        for (; i + e->graph_steps <= n_steps; i += e->graph_steps) {
             hipError_t err = hipGraphLaunch(e->exec, s);
             if (err != hipSuccess) return fail("engine_run: GraphLaunch: %s", hipGetErrorString(err));
+        }
+        for (; i < n_steps; ++i) {                  // (a remainder shorter than the captured graph: eager)
+            int rc = launch_step(e, with_epilogue, s, false);
+            if (rc) return rc;
         }
         return 0;
     }

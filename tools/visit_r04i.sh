@@ -1,0 +1,17 @@
+# write-through (sc1) output stores of the conv kernel's fast epilogue: same-box A/B against the default library
+set -u
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+for l in old new old new; do
+  if [ $l = new ]; then export CCDM_LIB=$PWD/tools/ab/p1.so; else unset CCDM_LIB; fi
+  python bench.py --steps 2 --warmup 1 --no-cpu-baseline --per-op gpurun_out/per_op_ab_$l.json 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$l', round(d['value'], 2), round(d['ms_per_denoise_step'],4), d['per_stage_us'], 'single', round(d['single_stream']['value'],2), round(d['single_stream']['ms_per_denoise_step'],4))"
+done
+python - <<'PY'
+import json
+a=json.load(open('gpurun_out/per_op_ab_old.json')); b=json.load(open('gpurun_out/per_op_ab_new.json'))
+for x,y in zip(a,b):
+    if abs(x['mean_us']-y['mean_us'])>0.03*x['mean_us']: print(x['op'], x['name'], x['shape'], round(x['mean_us'],1), '->', round(y['mean_us'],1))
+PY
