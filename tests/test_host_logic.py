@@ -25,6 +25,23 @@ def lidc_model(vote="confidence"):
                          "datasets.lidc", vote, None)
 
 
+def test_shipped_library_reads_no_environment_and_allocates_nothing():
+    """The product library imports neither getenv nor hipMalloc*: every A/B switch lives behind CCDM_EXPERIMENTS / CCDM_ABLATION builds
+    (include/ccdm_hip.h: no allocation inside, no global state besides the thread-local error string)."""
+    import subprocess
+    import __graft_entry__ as g
+    g.build()
+    try:
+        flavour = open(hip.LIB_PATH + ".flavour").read().strip()
+    except OSError:
+        flavour = "default"
+    if flavour != "default":
+        pytest.skip(f"in-tree library was linked from the {flavour!r} flavour")
+    syms = subprocess.run(["nm", "-D", "--undefined-only", hip.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    bad = [ln for ln in syms.splitlines() if any(t in ln for t in ("getenv", "hipMalloc", "hipHostMalloc", "hipMallocAsync"))]
+    assert not bad, bad
+
+
 def test_library_exports_every_declared_symbol():
     """The C-ABI library loads here (no GPU) and exports exactly what include/ccdm_hip.h declares."""
     import __graft_entry__ as g
