@@ -100,6 +100,7 @@ int launch_posterior(const ccdm_post_args& a, hipStream_t s);
 int launch_stats_fold(const double* in, int N, int S_in, int C, int S_out, double* out, hipStream_t s);
 int launch_attn_block(const ccdm_attn_block_args& a, hipStream_t s);
 int launch_resample(const ccdm_resample_args& a, hipStream_t s);
+int launch_stem(const ccdm_stem_args& a, hipStream_t s);
 bool attn_block_supported(int T, int C, int heads);
 
 }  // namespace ccdm

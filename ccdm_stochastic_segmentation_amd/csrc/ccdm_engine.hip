@@ -31,12 +31,13 @@ __global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ x, siz
 }
 
 struct Op {
-    int kind;   // 0 conv, 1 attention core, 2 statistics fold, 3 GroupNorm + qkv + attention core, 4 resample (updown ResBlocks)
+    int kind;   // 0 conv, 1 attention core, 2 statistics fold, 3 GroupNorm + qkv + attention core, 4 resample (updown ResBlocks), 5 stem conv
     ccdm_conv_args conv;
     const float* qkv; float* out; int N, T, C, heads, order;
     const double* fin; double* fout; int S_in, S_out;
     ccdm_attn_block_args ab;
     ccdm_resample_args rs;
+    ccdm_stem_args st;
 };
 
 static int launch_op(const Op& op, hipStream_t s) {
@@ -45,7 +46,8 @@ static int launch_op(const Op& op, hipStream_t s) {
         case 1: return launch_attention(op.qkv, op.out, op.N, op.T, op.T, op.C, op.heads, op.order, s);
         case 2: return launch_stats_fold(op.fin, op.N, op.S_in, op.C, op.S_out, op.fout, s);
         case 3: return launch_attn_block(op.ab, s);
-        default: return launch_resample(op.rs, s);
+        case 4: return launch_resample(op.rs, s);
+        default: return launch_stem(op.st, s);
     }
 }
 
@@ -209,6 +211,17 @@ extern "C" int ccdm_engine_add_resample(ccdm_engine* e, const ccdm_resample_args
     return (int)e->ops.size() - 1;
 }
 
+extern "C" int ccdm_engine_add_stem(ccdm_engine* e, const ccdm_stem_args* a) {
+    CCDM_REQUIRE(e && a, "engine_add_stem: null");
+    CCDM_REQUIRE(ccdm_stem_conv_supported(a->Cs, a->Cout, a->H, a->W, CCDM_PREC_F16X3), "engine_add_stem: Cs=%d Cout=%d %dx%d is not built", a->Cs, a->Cout, a->H, a->W);
+    Op op{};
+    op.kind = 5;
+    op.st = *a;
+    e->ops.push_back(op);
+    drop_graph(e);
+    return (int)e->ops.size() - 1;
+}
+
 extern "C" int ccdm_engine_set_epilogue(ccdm_engine* e, const ccdm_post_args* a) {
     CCDM_REQUIRE(e && a, "engine_set_epilogue: null");
     e->post = *a;
@@ -360,10 +373,12 @@ extern "C" int ccdm_engine_input_absmax(ccdm_engine* e, float* out, int row, voi
     for (size_t i = 0; i < e->ops.size() && !rc; ++i) {
         const Op& op = e->ops[i];
         if (op.kind == 0) rc = launch_conv_input_absmax(op.conv, out + i, s);
-        else if (op.kind == 1) {
-            const size_t n4 = (size_t)op.N * op.T * 3 * op.C / 4;
+        else if (op.kind == 5 || op.kind == 1) {
+            // (stem: the image channels of xin — its one-hot channels hold 0 / 1 or nothing; attention core: q, k, v)
+            const size_t n4 = op.kind == 5 ? (size_t)op.st.N * op.st.H * op.st.W * op.st.Cs / 4 : (size_t)op.N * op.T * 3 * op.C / 4;
+            const float* src = op.kind == 5 ? op.st.xin : op.qkv;
             const unsigned bx = (unsigned)(n4 / 256 < 1 ? 1 : (n4 / 256 > 1024 ? 1024 : n4 / 256));
-            hipLaunchKernelGGL(k_absmax, dim3(bx), dim3(256), 0, s, op.qkv, n4, out + i);
+            hipLaunchKernelGGL(k_absmax, dim3(bx), dim3(256), 0, s, src, n4, out + i);
             if (hipGetLastError() != hipSuccess) rc = fail("engine_input_absmax: attention operand probe failed to launch");
         }
     }
@@ -388,6 +403,8 @@ extern "C" int ccdm_engine_describe_op(const ccdm_engine* e, int i, char* buf, i
         snprintf(buf, buflen, "stats fold %d -> %d slices, C=%d", op.S_in, op.S_out, op.C);
     } else if (op.kind == 3) {
         snprintf(buf, buflen, "norm+qkv+attention T=%d C=%d heads=%d", op.ab.T, op.ab.C, op.ab.heads);
+    } else if (op.kind == 5) {
+        snprintf(buf, buflen, "stem conv3x3 onehot(%d)+image(%d)->%d @%dx%d stats", op.st.K, op.st.Cs - op.st.K, op.st.Cout, op.st.H, op.st.W);
     } else {
         snprintf(buf, buflen, "resample %s C=%d in%dx%d%s%s%s%s", op.rs.mode == CCDM_RESAMPLE_AVGPOOL2 ? "avgpool2" : "nearest-up2", op.rs.C, op.rs.Hin,
                  op.rs.Win, op.rs.stats ? " gn" : "", op.rs.act ? " silu" : "", op.rs.out_act ? " ->act" : "", op.rs.out_raw ? " ->raw" : "");

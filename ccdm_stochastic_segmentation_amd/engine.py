@@ -207,6 +207,30 @@ class SamplerEngine:
         self._fold_stats(out)
         return out
 
+    def _stem(self, wkey: str, cout: int) -> DevTensor:
+        """input_blocks[0] on the stem kernel (ccdm_stem.hip): the one-hot of x_t is built from the uint8 index while staging, the image
+        comes from xin's channels [K, Cs); (tap, channel)-major K axis.  The epilogue then has no one-hot to write (post.xin = NULL)."""
+        sd = self._sd
+        w = sd[wkey + ".weight"].numpy()
+        assert w.shape[0] == cout and w.shape[1] == self.K + self.C_img <= self.Cs == 4, (wkey, w.shape)
+        wdev = self._upload(hip.pack_stem_weight(w))
+        bias = self._upload(sd[wkey + ".bias"].numpy())
+        a = hip.StemArgs()
+        a.xt, a.xin, a.Cs, a.K = self.xt.data_ptr(), self.xin.ptr, self.Cs, self.K
+        a.w, a.bias = wdev.data_ptr(), bias.data_ptr()
+        a.N, a.H, a.W, a.Cout = self.N, self.H, self.W, cout
+        out = self._act(cout, self.H, self.W, True, self.lib.ccdm_conv_slices(self.H, self.W, 1, 3))
+        a.out, a.out_stats, a.out_slices = out.ptr, out.stats_ptr, out.slices
+        hip.check(self.lib.ccdm_engine_add_stem(self._handle, C.byref(a)), "engine_add_stem " + wkey)
+        self.op_names.append(wkey)
+        cin = self.Cs
+        self.op_info.append(dict(kind="conv", name=wkey, cin=cin, cout=cout, k=3, hin=self.H, win=self.W, hout=self.H, wout=self.W,
+                                 stride=1, up=False, subpixel=False, gn=False, skip=False, prec=hip.PREC_F16X3, skip_wide=False, stem=True,
+                                 io_bytes=4 * (cin * self.H * self.W + cout * self.H * self.W), gn_read_bytes=0,
+                                 weight_bytes=4 * cout * cin * 9, flop=2 * cin * cout * 9 * self.H * self.W))
+        self.stem_onehot_on_load = True
+        return out
+
     def _resample(self, x: DevTensor, mode: int, *, gn: Optional[str] = None, act: int = hip.ACT_NONE, want_act: bool, want_raw: bool,
                   name: str) -> Tuple[Optional[DevTensor], Optional[DevTensor]]:
         """AvgPool2d(2) / nearest x2 of `x`: (R(act(GroupNorm(x))), R(x)) — the two branches of an updown ResBlock (unet.py:243-248)."""
@@ -313,7 +337,11 @@ class SamplerEngine:
         for l in layers:
             cur = src if h is None else [h]
             if l.kind == "conv":
-                h = self._conv(cur, l.name, l.cout, 3)
+                if (cur[0] is self.xin and len(cur) == 1 and self.prec == hip.PREC_F16X3 and l.name not in self.f32_layers and not self.fine_slices
+                        and self.lib.ccdm_stem_conv_supported(self.Cs, l.cout, self.H, self.W, hip.PREC_F16X3)):
+                    h = self._stem(l.name, l.cout)
+                else:
+                    h = self._conv(cur, l.name, l.cout, 3)
             elif l.kind == "res":
                 h = self._res(l.name, l, cur)
             elif l.kind == "attn":
@@ -340,6 +368,7 @@ class SamplerEngine:
             raise hip.CcdmHipError("engine_create: " + hip.last_error())
         self.op_names: List[str] = []
         self.op_info: List[dict] = []
+        self.stem_onehot_on_load = False
 
         # --- time-conditioning parameters: every ResBlock's emb_layers.1 concatenated -----------------
         ted, mc = spec.time_embed_dim, spec.model_channels
@@ -418,7 +447,8 @@ class SamplerEngine:
         post.noise, post.noise_step_stride = 0, 0
         post.philox_seed, post.sample_offset = 0, 0
         post.xt_next = self.xt.data_ptr()
-        post.xin, post.xin_stride = self.xin.ptr, self.Cs
+        # (the stem kernel builds the one-hot from xt while staging: nothing reads xin's class channels, the epilogue does not write them)
+        post.xin, post.xin_stride = (0 if self.stem_onehot_on_load else self.xin.ptr), self.Cs
         post.out_probs, post.out_onehot, post.posterior_out = self.out_probs.data_ptr(), self.out_onehot.data_ptr(), 0
         self.flag = self._dev((1,), torch.int32, zero=True)      # sticky: a head output was not finite (F16X3 range overflow upstream)
         post.noise_row0, post.range_flag = 0, self.flag.data_ptr()

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define CCDM_ABI_VERSION 7
+#define CCDM_ABI_VERSION 8
 #define CCDM_MAX_CHANNELS 1024      /* max C0+C1 of a GroupNorm'ed conv input */
 #define CCDM_STATS_MAX_SLICES 64    /* partial-statistics slices per sample a GroupNorm consumer reads (more: ccdm_stats_fold) */
 #define CCDM_STATS_FOLD_SLICES 16   /* what ccdm_stats_fold reduces a larger slice count to */
@@ -149,6 +149,28 @@ typedef struct ccdm_resample_args {
     float* out_raw;
 } ccdm_resample_args;
 int ccdm_resample(const ccdm_resample_args* a, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * The stem conv for inputs of at most 4 channels (LIDC: 2 classes + 1 image channel), CCDM_PREC_F16X3:
+ *     h = conv3x3( cat([one_hot(x_t), image], 1) ) + bias                          unet.py:517 fed by unet.py:760
+ * x_t arrives as the uint8 class index the epilogue leaves and the one-hot is built while staging; the image is
+ * read from channels [K, Cs) of `xin` (its channels [0, K) are ignored — the epilogue need not write a one-hot there:
+ * ccdm_post_args.xin = NULL).  The K axis of the GEMM is (tap, channel): 3 k-steps instead of the general kernel's 9.
+ * Built for Cs == 4, H % 8 == 0, W % 32 == 0, Cout % 32 == 0 (ccdm_stem_conv_supported); out_slices = ccdm_conv_slices(H, W, 1, 3).
+ * Weights: ccdm_pack_stem_weight(oihw [Cout, Cin <= 4, 3, 3]).
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct ccdm_stem_args {
+    const uint8_t* xt;          /* dev [N,H*W] class index of x_t */
+    const float* xin;           /* dev NHWC fp32 [N,H,W,Cs]; channels [K, Cs): the conditioning image (zero beyond it) */
+    int32_t Cs, K;
+    const void* w; const float* bias;
+    int32_t N, H, W, Cout;
+    float* out;                 /* dev [N,H,W,Cout] */
+    double* out_stats; int32_t out_slices;
+} ccdm_stem_args;
+int ccdm_stem_conv_supported(int Cs, int Cout, int H, int W, int prec);
+size_t ccdm_pack_stem_weight(const float* oihw, int Cout, int Cin, void* out);      /* out == NULL: returns the byte count */
+int ccdm_stem_conv(const ccdm_stem_args* a, void* stream);
 
 /* F16X3 range diagnostics: max |a| over everything this conv stages — the main input after GroupNorm (+ SiLU) where it normalises on
  * load, raw otherwise, and the raw input of the fused 1x1 skip segment — before the kernel's 2^4 pre-scale; Inf if any value is not
@@ -322,6 +344,7 @@ int ccdm_engine_add_attention(ccdm_engine* e, const float* qkv, float* out, int 
 int ccdm_engine_add_norm_qkv_attention(ccdm_engine* e, const ccdm_attn_block_args* a);
 int ccdm_engine_add_stats_fold(ccdm_engine* e, const double* in, int N, int S_in, int C, int S_out, double* out);
 int ccdm_engine_add_resample(ccdm_engine* e, const ccdm_resample_args* a);
+int ccdm_engine_add_stem(ccdm_engine* e, const ccdm_stem_args* a);
 int ccdm_engine_set_epilogue(ccdm_engine* e, const ccdm_post_args* a);      /* run after the ops of each step */
 int ccdm_engine_num_ops(const ccdm_engine* e);
 int ccdm_engine_num_captures(const ccdm_engine* e);   /* how often ccdm_engine_run has captured + instantiated the step's HIP graph so far */

@@ -194,3 +194,25 @@ def norm_qkv_attention(x_nhwc, norm_w, norm_b, qkv_w, qkv_b, heads: int, new_ord
     hip.check(lib.ccdm_norm_qkv_attention(C.byref(a), 0), "norm_qkv_attention")
     sync()
     return out
+
+
+def stem_conv(xt_idx, xin_nhwc, K, weight, bias):
+    """ccdm_stem_conv: xt_idx uint8 cuda [N,H,W]; xin NHWC cuda [N,H,W,4] (image in channels [K, 4)); weight [Cout, Cin<=4, 3, 3].
+    Returns (out NHWC cuda, stats [N, slices, Cout, 2])."""
+    lib = hip.load()
+    N, H, W, Cs = xin_nhwc.shape
+    w = np.ascontiguousarray(weight, dtype=np.float32)
+    cout = w.shape[0]
+    wdev = torch.from_numpy(hip.pack_stem_weight(w)).to(DEV)
+    bdev = torch.as_tensor(np.asarray(bias, dtype=np.float32)).to(DEV)
+    S = lib.ccdm_conv_slices(H, W, 1, 3)
+    out = torch.empty((N, H, W, cout), device=DEV)
+    st = torch.empty((N, S, cout, 2), dtype=torch.float64, device=DEV)
+    a = hip.StemArgs()
+    a.xt, a.xin, a.Cs, a.K = xt_idx.data_ptr(), xin_nhwc.data_ptr(), Cs, K
+    a.w, a.bias = wdev.data_ptr(), bdev.data_ptr()
+    a.N, a.H, a.W, a.Cout = N, H, W, cout
+    a.out, a.out_stats, a.out_slices = out.data_ptr(), st.data_ptr(), S
+    hip.check(lib.ccdm_stem_conv(C.byref(a), 0), "stem_conv")
+    sync()
+    return out, st

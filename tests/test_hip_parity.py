@@ -349,6 +349,47 @@ def test_conv_few_pixel_kernel_fused_skip(U, c0, c1, cout, H, W):
     test_conv_with_fused_skip(U, hip.PREC_F16X3, c0, c1, cout, H, W)
 
 
+@pytest.mark.parametrize("K,cimg,cout,H,W", [(2, 1, 32, 128, 128), (2, 1, 64, 16, 64), (3, 1, 32, 8, 32), (2, 2, 32, 24, 96), (1, 3, 32, 40, 32)])
+def test_stem_conv_onehot_on_load(U, K, cimg, cout, H, W):
+    """ccdm_stem.hip: conv3x3(cat[one_hot(x_t), image]) with the one-hot built from the uint8 index while staging and a (tap, channel)
+    K axis — against the fp64 operator, against the general kernel on the materialised input, run-to-run and shard bit-identity,
+    statistics = those of what was stored.  Whatever sits in xin's class channels is ignored."""
+    rng = np.random.default_rng(K * 100 + H + cout)
+    N = 3
+    idx = torch.from_numpy(rng.integers(0, K, (N, H, W))).to(torch.uint8)
+    img = rnd(rng, N, cimg, H, W) * 1.3 - 0.2
+    w = rnd(rng, cout, K + cimg, 3, 3) / np.sqrt((K + cimg) * 9)
+    b = rnd(rng, cout, scale=0.1)
+    x = torch.cat([F.one_hot(idx.long(), K).permute(0, 3, 1, 2).float(), img], 1)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    xin = torch.zeros((N, H, W, 4))
+    xin[..., :K] = 77.0                                       # garbage in the class channels: must not be read
+    xin[..., K:K + cimg] = img.permute(0, 2, 3, 1)
+    xin_d, idx_d = xin.to(U.DEV), idx.to(U.DEV)
+    out, st = U.stem_conv(idx_d, xin_d, K, w.numpy(), b.numpy())
+    got = U.bchw(out)
+    np.testing.assert_allclose(got.numpy(), ref.float().numpy(), rtol=0, atol=2e-5)
+    # the general kernel on the materialised [one-hot | image | 0] input: same products, another summation order
+    xm = torch.zeros((N, H, W, 4))
+    xm[..., :K + cimg] = x.permute(0, 2, 3, 1)
+    wp = np.zeros((cout, 4, 3, 3), np.float32)
+    wp[:, :K + cimg] = w.numpy()
+    gen, gst = U.conv2d([xm.to(U.DEV)], wp, b.numpy(), 3, prec=hip.PREC_F16X3)
+    np.testing.assert_allclose(out.cpu().numpy(), gen.cpu().numpy(), rtol=0, atol=4e-6)
+    np.testing.assert_allclose(st.sum(1).cpu().numpy(), gst.sum(1).cpu().numpy(), rtol=2e-6, atol=1e-4)      # (slice counts may differ: the kernel owns its tiling)
+    gd = got.double()
+    np.testing.assert_allclose(st.cpu().sum(1)[..., 0].numpy(), gd.sum((2, 3)).numpy(), rtol=0, atol=2e-6 * gd.abs().sum((2, 3)).max().item())
+    np.testing.assert_allclose(st.cpu().sum(1)[..., 1].numpy(), (gd * gd).sum((2, 3)).numpy(), rtol=2e-6, atol=0)
+    again, st2 = U.stem_conv(idx_d, xin_d, K, w.numpy(), b.numpy())
+    assert torch.equal(out, again) and torch.equal(st, st2), "run-to-run nondeterminism"
+    one, st1 = U.stem_conv(idx_d[N - 1:].contiguous(), xin_d[N - 1:].contiguous(), K, w.numpy(), b.numpy())
+    assert torch.equal(one, out[N - 1:]) and torch.equal(st1, st[N - 1:])
+    lib = hip.load()
+    assert lib.ccdm_stem_conv_supported(4, cout, H, W, hip.PREC_F16X3) == 1
+    assert lib.ccdm_stem_conv_supported(4, cout, H, W + 8, hip.PREC_F16X3) == 0 and lib.ccdm_stem_conv_supported(8, cout, H, W, hip.PREC_F16X3) == 0
+    assert lib.ccdm_stem_conv_supported(4, cout, H, W, hip.PREC_F32) == 0
+
+
 def test_conv_rejects_bad_args(U):
     x = torch.zeros((1, 8, 8, 6), device=U.DEV)
     with pytest.raises(hip.CcdmHipError, match="multiples of 4"):
