@@ -325,7 +325,7 @@ def main():
         # report.  (The Upsample conv that lands on HxW runs the sub-pixel instantiation, the convs with a fused 1x1 skip of 32-channel
         # sources the core-only skip-chunk instantiation: other symbols — in the per-op table, not in this class.)
         dom_ops = [i for i, o in enumerate(info) if o["kind"] == "conv" and o["k"] == 3 and o["stride"] == 1 and (o["hout"], o["wout"]) == (H, W)
-                   and not o.get("subpixel") and not o.get("skip_wide") and not o.get("stem")]
+                   and not o.get("subpixel") and not o.get("skip_wide") and not o.get("stem") and not o.get("head_fused")]
         attn_ops = [i for i, o in enumerate(info) if o["kind"] == "attention" and o["T"] >= 2048]
         attn = max(attn_ops, key=lambda i: info[i]["T"]) if attn_ops else None
         for i in range(len(info)):

@@ -101,6 +101,7 @@ int launch_stats_fold(const double* in, int N, int S_in, int C, int S_out, doubl
 int launch_attn_block(const ccdm_attn_block_args& a, hipStream_t s);
 int launch_resample(const ccdm_resample_args& a, hipStream_t s);
 int launch_stem(const ccdm_stem_args& a, hipStream_t s);
+int launch_head(const ccdm_head_args& a, const ccdm_post_args& post, hipStream_t s);
 bool attn_block_supported(int T, int C, int heads);
 
 }  // namespace ccdm

@@ -31,17 +31,19 @@ __global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ x, siz
 }
 
 struct Op {
-    int kind;   // 0 conv, 1 attention core, 2 statistics fold, 3 GroupNorm + qkv + attention core, 4 resample (updown ResBlocks), 5 stem conv
+    int kind;   // 0 conv, 1 attention core, 2 statistics fold, 3 GroupNorm + qkv + attention core, 4 resample (updown ResBlocks), 5 stem conv, 6 head conv + epilogue
     ccdm_conv_args conv;
     const float* qkv; float* out; int N, T, C, heads, order;
     const double* fin; double* fout; int S_in, S_out;
     ccdm_attn_block_args ab;
     ccdm_resample_args rs;
     ccdm_stem_args st;
+    ccdm_head_args hd;
 };
 
 static int launch_op(const Op& op, hipStream_t s) {
     switch (op.kind) {
+        case 6: return fail("engine: the head + epilogue op is launched with the epilogue's arguments");
         case 0: return launch_conv(op.conv, s);
         case 1: return launch_attention(op.qkv, op.out, op.N, op.T, op.T, op.C, op.heads, op.order, s);
         case 2: return launch_stats_fold(op.fin, op.N, op.S_in, op.C, op.S_out, op.fout, s);
@@ -128,11 +130,15 @@ static int launch_step(ccdm_engine* e, int with_epilogue, hipStream_t s, bool pr
             if (it != e->taps.end() && (size_t)(2 * it->second.n + 1) < it->second.ev.size()) tp = &it->second;
         }
         if (tp) (void)hipEventRecord(tp->ev[2 * tp->n], s);
-        int rc = launch_op(op, s);
+        int rc;
+        if (op.kind == 6) {
+            // head conv + epilogue in one launch: the epilogue's current arguments travel with it
+            rc = (with_epilogue && e->has_post) ? launch_head(op.hd, e->post, s) : fail("engine_run: this step ends in a fused head + epilogue op: with_epilogue must be 1 and an epilogue set");
+        } else rc = launch_op(op, s);
         if (tp) { (void)hipEventRecord(tp->ev[2 * tp->n + 1], s); tp->n++; }
         if (rc) return rc;
     }
-    if (with_epilogue && e->has_post) {
+    if (with_epilogue && e->has_post && !(e->ops.size() && e->ops.back().kind == 6)) {
         int rc = launch_posterior(e->post, s);
         if (rc) return rc;
     }
@@ -217,6 +223,17 @@ extern "C" int ccdm_engine_add_stem(ccdm_engine* e, const ccdm_stem_args* a) {
     Op op{};
     op.kind = 5;
     op.st = *a;
+    e->ops.push_back(op);
+    drop_graph(e);
+    return (int)e->ops.size() - 1;
+}
+
+extern "C" int ccdm_engine_add_head_posterior(ccdm_engine* e, const ccdm_head_args* a) {
+    CCDM_REQUIRE(e && a, "engine_add_head_posterior: null");
+    CCDM_REQUIRE(ccdm_head_posterior_supported(a->C, a->K, a->H, a->W, CCDM_PREC_F16X3), "engine_add_head_posterior: C=%d K=%d %dx%d is not built", a->C, a->K, a->H, a->W);
+    Op op{};
+    op.kind = 6;
+    op.hd = *a;
     e->ops.push_back(op);
     drop_graph(e);
     return (int)e->ops.size() - 1;
@@ -373,6 +390,13 @@ extern "C" int ccdm_engine_input_absmax(ccdm_engine* e, float* out, int row, voi
     for (size_t i = 0; i < e->ops.size() && !rc; ++i) {
         const Op& op = e->ops[i];
         if (op.kind == 0) rc = launch_conv_input_absmax(op.conv, out + i, s);
+        else if (op.kind == 6) {
+            ccdm_conv_args c{};                  // what the head stages: SiLU(GroupNorm(x))
+            c.in0 = op.hd.x; c.C0 = op.hd.C; c.stats0 = op.hd.stats; c.slices0 = op.hd.slices; c.gamma = op.hd.gamma; c.beta = op.hd.beta;
+            c.eps = op.hd.eps; c.act = CCDM_ACT_SILU; c.N = op.hd.N; c.Hin = c.Hout = op.hd.H; c.Win = c.Wout = op.hd.W; c.ksize = 3; c.stride = 1;
+            c.emb_off = -1; c.prec = CCDM_PREC_F16X3;
+            rc = launch_conv_input_absmax(c, out + i, s);
+        }
         else if (op.kind == 5 || op.kind == 1) {
             // (stem: the image channels of xin — its one-hot channels hold 0 / 1 or nothing; attention core: q, k, v)
             const size_t n4 = op.kind == 5 ? (size_t)op.st.N * op.st.H * op.st.W * op.st.Cs / 4 : (size_t)op.N * op.T * 3 * op.C / 4;
@@ -403,6 +427,8 @@ extern "C" int ccdm_engine_describe_op(const ccdm_engine* e, int i, char* buf, i
         snprintf(buf, buflen, "stats fold %d -> %d slices, C=%d", op.S_in, op.S_out, op.C);
     } else if (op.kind == 3) {
         snprintf(buf, buflen, "norm+qkv+attention T=%d C=%d heads=%d", op.ab.T, op.ab.C, op.ab.heads);
+    } else if (op.kind == 6) {
+        snprintf(buf, buflen, "head gn silu conv3x3 %d->%d @%dx%d + posterior / draw", op.hd.C, op.hd.K, op.hd.H, op.hd.W);
     } else if (op.kind == 5) {
         snprintf(buf, buflen, "stem conv3x3 onehot(%d)+image(%d)->%d @%dx%d stats", op.st.K, op.st.Cs - op.st.K, op.st.Cout, op.st.H, op.st.W);
     } else {

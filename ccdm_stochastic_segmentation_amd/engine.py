@@ -426,7 +426,11 @@ class SamplerEngine:
             wk, bk = self._sd["out.2.weight"], self._sd["out.2.bias"]
             self._sd["out.2.weight"] = torch.cat([wk, torch.zeros((Kp - K,) + tuple(wk.shape[1:]))], 0)
             self._sd["out.2.bias"] = torch.cat([bk, torch.zeros(Kp - K)], 0)
-        self.head = self._conv([h], "out.2", Kp, 3, gn="out.0", act=hip.ACT_SILU, stats=False)
+        # few classes on a 32-channel head (LIDC): head conv + step epilogue in ONE launch (ccdm_head.hip) — the logits never reach memory
+        self.head_fused = bool(self.prec == hip.PREC_F16X3 and "out.2" not in self.f32_layers and not self.fine_slices and h.stats is not None
+                               and lib.ccdm_head_posterior_supported(h.C, K, H, W, hip.PREC_F16X3))
+        self._head_src = h
+        self.head = None if self.head_fused else self._conv([h], "out.2", Kp, 3, gn="out.0", act=hip.ACT_SILU, stats=False)
         # optional parallel head (unet.py:716-726,805-807): GN -> SiLU -> conv to K-1 logits, no softmax; evaluated on every
         # U-Net call like the reference's forward does
         self.head_ce: Optional[DevTensor] = None
@@ -438,10 +442,27 @@ class SamplerEngine:
                 self._sd["out_ce.2.weight"] = torch.cat([wk, torch.zeros((Kcp - Kc,) + tuple(wk.shape[1:]))], 0)
                 self._sd["out_ce.2.bias"] = torch.cat([bk, torch.zeros(Kcp - Kc)], 0)
             self.head_ce = self._conv([h], "out_ce.2", Kcp, 3, gn="out_ce.0", act=hip.ACT_SILU, stats=False)
+        if self.head_fused:          # (after the optional ce head: the fused op must be the last of the step)
+            sdw = self._sd
+            a = hip.HeadArgs()
+            a.x, a.stats, a.slices = h.ptr, h.stats_ptr, h.slices
+            a.gamma = self._upload(sdw["out.0.weight"].numpy()).data_ptr()
+            a.beta = self._upload(sdw["out.0.bias"].numpy()).data_ptr()
+            a.eps = GN_EPS
+            a.w = self._upload(hip.pack_head_weight(sdw["out.2.weight"].numpy()[:K])).data_ptr()
+            a.bias = self._upload(sdw["out.2.bias"].numpy()[:K]).data_ptr()
+            a.N, a.H, a.W, a.C, a.K = N, H, W, h.C, K
+            a.logits_out = 0
+            hip.check(lib.ccdm_engine_add_head_posterior(self._handle, C.byref(a)), "engine_add_head_posterior")
+            self.op_names.append("out.2")
+            self.op_info.append(dict(kind="conv", name="out.2", cin=h.C, cout=Kp, k=3, hin=H, win=W, hout=H, wout=W, stride=1, up=False,
+                                     subpixel=False, gn=True, skip=False, prec=hip.PREC_F16X3, skip_wide=False, head_fused=True,
+                                     io_bytes=4 * (h.C * H * W + Kp * H * W), gn_read_bytes=4 * h.C * H * W, weight_bytes=4 * Kp * h.C * 9,
+                                     flop=2 * h.C * Kp * 9 * H * W))
         self.n_unet_ops = lib.ccdm_engine_num_ops(self._handle)
 
         post = hip.PostArgs()
-        post.head, post.softmax, post.head_stride = self.head.ptr, int(spec.softmax_output), self.head.C
+        post.head, post.softmax, post.head_stride = (0 if self.head_fused else self.head.ptr), int(spec.softmax_output), (Kp if self.head_fused else self.head.C)
         post.xt, post.N, post.HW, post.K = self.xt.data_ptr(), N, H * W, K
         post.step_table, post.step_ptr = self.step_table.data_ptr(), 0
         post.noise, post.noise_step_stride = 0, 0

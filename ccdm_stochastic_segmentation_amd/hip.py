@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("CCDM_LIB") or os.path.join(_HERE, "libccdm_hip.so")      # CCDM_LIB: A/B two builds on one GPU box
 CSRC = os.path.join(_HERE, "csrc")
-SOURCES = ["ccdm_conv.hip", "ccdm_conv_ks.hip", "ccdm_stem.hip", "ccdm_conv1x1.hip", "ccdm_misc.hip", "ccdm_attention.hip", "ccdm_attn_block.hip", "ccdm_sampler.hip", "ccdm_metrics.hip", "ccdm_range.hip", "ccdm_resample.hip", "ccdm_engine.hip"]
+SOURCES = ["ccdm_conv.hip", "ccdm_conv_ks.hip", "ccdm_stem.hip", "ccdm_head.hip", "ccdm_conv1x1.hip", "ccdm_misc.hip", "ccdm_attention.hip", "ccdm_attn_block.hip", "ccdm_sampler.hip", "ccdm_metrics.hip", "ccdm_range.hip", "ccdm_resample.hip", "ccdm_engine.hip"]
 # CCDM_EXPERIMENTS=1 builds add the measured-and-rejected kernels of tools/experiments/ and the environment switches the A/B tools use
 # (exp_env in ccdm_common.h); the shipped library contains neither
 EXPERIMENT_SOURCES = [os.path.join(ROOT, "tools", "experiments", "ccdm_conv_pc.hip"), os.path.join(ROOT, "tools", "experiments", "ccdm_attention_split.hip")]
@@ -34,7 +34,7 @@ STEP_SAMPLE, STEP_LAST_CONFIDENCE, STEP_LAST_MAJORITY, STEP_LAST_KEEP, STEP_SOFT
 STATS_MAX_SLICES = 64       # CCDM_STATS_MAX_SLICES: what a GroupNorm consumer reads
 F16X3_LIMIT = 4094.0        # CCDM_F16X3_LIMIT: the fp16 split is exact for staged |a| below this
 STATS_FOLD_SLICES = 16      # CCDM_STATS_FOLD_SLICES: what the engine folds a larger slice count to
-ABI_VERSION = 8          # CCDM_ABI_VERSION of include/ccdm_hip.h
+ABI_VERSION = 9          # CCDM_ABI_VERSION of include/ccdm_hip.h
 
 
 class ConvArgs(C.Structure):
@@ -111,6 +111,16 @@ class StemArgs(C.Structure):
     ]
 
 
+class HeadArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("stats", C.c_void_p), ("slices", C.c_int32),
+        ("gamma", C.c_void_p), ("beta", C.c_void_p), ("eps", C.c_float),
+        ("w", C.c_void_p), ("bias", C.c_void_p),
+        ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("K", C.c_int32),
+        ("logits_out", C.c_void_p),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/ccdm_hip.h declares
 SIGNATURES = {
     "ccdm_version": (C.c_int, []),
@@ -132,6 +142,10 @@ SIGNATURES = {
     "ccdm_engine_add_stats_fold": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ccdm_engine_add_resample": (C.c_int, [C.c_void_p, C.POINTER(ResampleArgs)]),
     "ccdm_engine_add_stem": (C.c_int, [C.c_void_p, C.POINTER(StemArgs)]),
+    "ccdm_engine_add_head_posterior": (C.c_int, [C.c_void_p, C.POINTER(HeadArgs)]),
+    "ccdm_head_posterior_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ccdm_pack_head_weight": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "ccdm_head_posterior": (C.c_int, [C.POINTER(HeadArgs), C.POINTER(PostArgs), C.c_void_p]),
     "ccdm_stem_conv_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ccdm_pack_stem_weight": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "ccdm_stem_conv": (C.c_int, [C.POINTER(StemArgs), C.c_void_p]),
@@ -289,6 +303,21 @@ def pack_conv_weight(w, ksize: int, prec: int = PREC_F32, cout_absmax=None):
         raise CcdmHipError("pack_conv_weight: " + last_error())
     out = np.empty(nbytes, dtype=np.uint8)
     lib.ccdm_pack_conv_weight_ex(w.ctypes.data, cout, cin, ksize, prec, amp, out.ctypes.data)
+    return out
+
+
+def pack_head_weight(w):
+    """Head conv weight out.2 [K, 32, 3, 3] -> the taps-as-columns fragments of ccdm_head_posterior (host-side, no GPU needed)."""
+    import numpy as np
+    lib = load()
+    w = np.ascontiguousarray(w, dtype=np.float32)
+    k, cin = int(w.shape[0]), int(w.shape[1])
+    assert w.shape == (k, cin, 3, 3), w.shape
+    nbytes = lib.ccdm_pack_head_weight(None, k, cin, None)
+    if nbytes == 0:
+        raise CcdmHipError("pack_head_weight: " + last_error())
+    out = np.empty(nbytes, dtype=np.uint8)
+    lib.ccdm_pack_head_weight(w.ctypes.data, k, cin, out.ctypes.data)
     return out
 
 

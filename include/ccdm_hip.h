@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define CCDM_ABI_VERSION 8
+#define CCDM_ABI_VERSION 9
 #define CCDM_MAX_CHANNELS 1024      /* max C0+C1 of a GroupNorm'ed conv input */
 #define CCDM_STATS_MAX_SLICES 64    /* partial-statistics slices per sample a GroupNorm consumer reads (more: ccdm_stats_fold) */
 #define CCDM_STATS_FOLD_SLICES 16   /* what ccdm_stats_fold reduces a larger slice count to */
@@ -281,6 +281,26 @@ typedef struct ccdm_post_args {
 int ccdm_posterior_sample(const ccdm_post_args* a, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * The head of the U-Net and the epilogue above in ONE launch, for few classes (9 K <= 32) and 32 head channels, CCDM_PREC_F16X3:
+ *     logits = conv3x3(SiLU(GroupNorm32(x))) + bias   (self.out, unet.py:701-707)   ->   ccdm_posterior_sample's arithmetic on them
+ * (the same device function: identical bits from identical logits); the logits never reach memory.  The conv's taps are the N
+ * dimension of a 1x1 product over the halo tile (9 K columns), summed per pixel afterwards: results equal the general kernel's to fp32
+ * rounding.  `post` is a ccdm_post_args whose head / head_stride / xin fields are unused (x_t travels as the uint8 index).
+ * Built for C == 32, 2 <= K <= 3, H % 8 == 0, W % 32 == 0 (ccdm_head_posterior_supported).  Weights: ccdm_pack_head_weight.
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct ccdm_head_args {
+    const float* x;             /* dev NHWC fp32 [N,H,W,C]: the last ResBlock's output */
+    const double* stats; int32_t slices;        /* its partial statistics [N,slices,C,2] */
+    const float* gamma; const float* beta; float eps;       /* out.0 (GroupNorm32) */
+    const void* w; const float* bias;           /* out.2: ccdm_pack_head_weight(oihw [K,C,3,3]); dev [K] */
+    int32_t N, H, W, C, K;
+    float* logits_out;          /* dev [N,H*W,K] optional tap of the logits (tests), or NULL */
+} ccdm_head_args;
+int ccdm_head_posterior_supported(int C, int K, int H, int W, int prec);
+size_t ccdm_pack_head_weight(const float* oihw, int K, int Cin, void* out);         /* out == NULL: returns the byte count */
+int ccdm_head_posterior(const ccdm_head_args* a, const ccdm_post_args* post, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * LIDC metrics, device part: for every image and every pair (i, j) of class-index maps
  * a[img][i], b[img][j], the per-class pixel counts out[img][i][j][k] = {|a==k & b==k|, |a==k | b==k|}.
  * Replaces the [B,S,S',HW,K] boolean broadcast of `batched_distance` / `iou`
@@ -345,6 +365,9 @@ int ccdm_engine_add_norm_qkv_attention(ccdm_engine* e, const ccdm_attn_block_arg
 int ccdm_engine_add_stats_fold(ccdm_engine* e, const double* in, int N, int S_in, int C, int S_out, double* out);
 int ccdm_engine_add_resample(ccdm_engine* e, const ccdm_resample_args* a);
 int ccdm_engine_add_stem(ccdm_engine* e, const ccdm_stem_args* a);
+/* the LAST op of the step: head conv + the epilogue set by ccdm_engine_set_epilogue in one launch (no separate epilogue launch then;
+ * ccdm_engine_run needs with_epilogue = 1) */
+int ccdm_engine_add_head_posterior(ccdm_engine* e, const ccdm_head_args* a);
 int ccdm_engine_set_epilogue(ccdm_engine* e, const ccdm_post_args* a);      /* run after the ops of each step */
 int ccdm_engine_num_ops(const ccdm_engine* e);
 int ccdm_engine_num_captures(const ccdm_engine* e);   /* how often ccdm_engine_run has captured + instantiated the step's HIP graph so far */

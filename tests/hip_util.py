@@ -216,3 +216,45 @@ def stem_conv(xt_idx, xin_nhwc, K, weight, bias):
     hip.check(lib.ccdm_stem_conv(C.byref(a), 0), "stem_conv")
     sync()
     return out, st
+
+
+def head_posterior(x_nhwc, gamma, beta, weight, bias, xt_idx, a, c, mode, *, softmax=True, noise=None, philox_seed=0, sample_offset=0, step=0):
+    """ccdm_head_posterior: x [N,H,W,32] cuda; weight [K,32,3,3]; xt_idx uint8 [N,H*W] cuda.  Returns dict of outputs (cpu) incl. the
+    logits tap."""
+    lib = hip.load()
+    N, H, W, Cc = x_nhwc.shape
+    w = np.ascontiguousarray(weight, dtype=np.float32)
+    K = w.shape[0]
+    HW = H * W
+    st = gn_stats(x_nhwc, 4)
+    dev = [torch.from_numpy(np.ascontiguousarray(v)).to(DEV) for v in (hip.pack_head_weight(w), np.asarray(bias, np.float32), np.asarray(gamma, np.float32),
+                                                                       np.asarray(beta, np.float32))]
+    table = torch.zeros((step + 1, 4), dtype=torch.float32)
+    table[step, 0], table[step, 1], table[step, 2] = a, c, float(mode)
+    table = table.to(DEV)
+    stepbuf = torch.tensor([step], dtype=torch.int32, device=DEV)
+    xt_next = torch.full((N, HW), 255, dtype=torch.uint8, device=DEV)
+    probs = torch.zeros((N, HW, K), device=DEV)
+    onehot = torch.zeros((N, HW, K), dtype=torch.int64, device=DEV)
+    post = torch.zeros((N, HW, K), device=DEV)
+    logits = torch.zeros((N, HW, K), device=DEV)
+    flag = torch.zeros((1,), dtype=torch.int32, device=DEV)
+    h = hip.HeadArgs()
+    h.x, h.stats, h.slices = x_nhwc.data_ptr(), st.data_ptr(), 4
+    h.gamma, h.beta, h.eps = dev[2].data_ptr(), dev[3].data_ptr(), 1e-5
+    h.w, h.bias = dev[0].data_ptr(), dev[1].data_ptr()
+    h.N, h.H, h.W, h.C, h.K = N, H, W, Cc, K
+    h.logits_out = logits.data_ptr()
+    p = hip.PostArgs()
+    p.softmax, p.xt = int(softmax), xt_idx.data_ptr()
+    p.N, p.HW, p.K = N, HW, K
+    p.step_table, p.step_ptr = table.data_ptr(), stepbuf.data_ptr()
+    if noise is not None:
+        p.noise, p.noise_step_stride = noise.data_ptr(), N * HW * K
+    p.philox_seed, p.sample_offset = philox_seed, sample_offset
+    p.xt_next = xt_next.data_ptr()
+    p.out_probs, p.out_onehot, p.posterior_out = probs.data_ptr(), onehot.data_ptr(), post.data_ptr()
+    p.range_flag = flag.data_ptr()
+    hip.check(lib.ccdm_head_posterior(C.byref(h), C.byref(p), 0), "head_posterior")
+    sync()
+    return dict(xt_next=xt_next.cpu(), probs=probs.cpu(), onehot=onehot.cpu(), posterior=post.cpu(), logits=logits.cpu(), flag=int(flag.item()))

@@ -390,6 +390,65 @@ def test_stem_conv_onehot_on_load(U, K, cimg, cout, H, W):
     assert lib.ccdm_stem_conv_supported(4, cout, H, W, hip.PREC_F32) == 0
 
 
+@pytest.mark.parametrize("K,H,W", [(2, 128, 128), (2, 16, 64), (3, 8, 32), (2, 24, 96)])
+def test_head_conv_fused_with_the_epilogue(U, K, H, W):
+    """ccdm_head.hip: GroupNorm -> SiLU -> conv3x3 to K logits (taps as the N dimension of a 1x1 product over the halo tile) and the step
+    epilogue in one launch — logits against the fp64 operator and against the general kernel; every epilogue output equals what the
+    stand-alone epilogue kernel makes of THE SAME logits, bit for bit (one shared device function), in all three step modes; a
+    non-finite activation raises the range flag; run-to-run and shard bit-identity."""
+    rng = np.random.default_rng(K + H + W)
+    N, Cc = 3, 32
+    x = rnd(rng, N, Cc, H, W) * 1.7 + 0.2
+    gamma, beta = 1 + rnd(rng, Cc, scale=0.2), rnd(rng, Cc, scale=0.2)
+    w = rnd(rng, K, Cc, 3, 3) / np.sqrt(Cc * 9) * 2.0
+    b = rnd(rng, K, scale=0.3)
+    ref = F.conv2d(F.silu(F.group_norm(x.double(), 32, gamma.double(), beta.double(), 1e-5)), w.double(), b.double(), padding=1)
+    xs = U.nhwc(x)
+    xt = torch.from_numpy(rng.integers(0, K, (N, H * W))).to(torch.uint8).to(U.DEV)
+    noise = torch.from_numpy(rng.exponential(1.0, (N, H * W, K)).astype(np.float32)).to(U.DEV)
+    al, cu = 0.93, 0.41
+    for mode in (hip.STEP_SAMPLE, hip.STEP_LAST_CONFIDENCE, hip.STEP_LAST_MAJORITY):
+        got = U.head_posterior(xs, gamma.numpy(), beta.numpy(), w.numpy(), b.numpy(), xt, al, cu, mode, noise=noise)
+        logits = got["logits"].reshape(N, H, W, K).permute(0, 3, 1, 2)
+        np.testing.assert_allclose(logits.numpy(), ref.float().numpy(), rtol=0, atol=2e-5)
+        assert got["flag"] == 0
+        # the stand-alone epilogue on the same logits
+        alone = U.posterior_sample(got["logits"].to(U.DEV), xt, al, cu, mode, noise=noise)
+        assert torch.equal(got["posterior"], alone["posterior"])
+        if mode == hip.STEP_SAMPLE:
+            assert torch.equal(got["xt_next"], alone["xt_next"])
+        elif mode == hip.STEP_LAST_CONFIDENCE:
+            assert torch.equal(got["probs"], alone["probs"])
+        else:
+            assert torch.equal(got["onehot"], alone["onehot"]) and torch.equal(got["xt_next"], alone["xt_next"])
+    # device RNG: same Philox counters as the stand-alone kernel (pixel, global sample index, step)
+    g1 = U.head_posterior(xs, gamma.numpy(), beta.numpy(), w.numpy(), b.numpy(), xt, al, cu, hip.STEP_SAMPLE, philox_seed=77, sample_offset=5, step=3)
+    a1 = U.posterior_sample(g1["logits"].to(U.DEV), xt, al, cu, hip.STEP_SAMPLE, philox_seed=77, sample_offset=5, step=3)
+    assert torch.equal(g1["xt_next"], a1["xt_next"])
+    # the general conv kernel's logits: same products, another summation order
+    wp = np.zeros((4, Cc, 3, 3), np.float32)
+    wp[:K] = w.numpy()
+    bp = np.zeros(4, np.float32)
+    bp[:K] = b.numpy()
+    gen, _ = U.conv2d([xs], wp, bp, 3, stats=[U.gn_stats(xs, 4)], gamma=gamma.numpy(), beta=beta.numpy(), act=hip.ACT_SILU, prec=hip.PREC_F16X3,
+                      want_stats=False)
+    np.testing.assert_allclose(g1["logits"].reshape(N, H, W, K).numpy(), gen.cpu().numpy()[..., :K], rtol=0, atol=6e-6)
+    # determinism and shard invariance
+    g2 = U.head_posterior(xs, gamma.numpy(), beta.numpy(), w.numpy(), b.numpy(), xt, al, cu, hip.STEP_SAMPLE, philox_seed=77, sample_offset=5, step=3)
+    assert torch.equal(g1["logits"], g2["logits"]) and torch.equal(g1["xt_next"], g2["xt_next"])
+    one = U.head_posterior(xs[N - 1:].contiguous(), gamma.numpy(), beta.numpy(), w.numpy(), b.numpy(), xt[N - 1:].contiguous(), al, cu, hip.STEP_SAMPLE,
+                           philox_seed=77, sample_offset=5 + N - 1, step=3)
+    assert torch.equal(one["logits"], g1["logits"][N - 1:]) and torch.equal(one["xt_next"], g1["xt_next"][N - 1:])
+    # a non-finite staged value reaches the logits and raises the flag
+    xbad = xs.clone()
+    xbad[1, H // 2, W // 2, 5] = float("inf")
+    bad = U.head_posterior(xbad, gamma.numpy(), beta.numpy(), w.numpy(), b.numpy(), xt, al, cu, hip.STEP_SAMPLE, noise=noise)
+    assert bad["flag"] == 1
+    lib = hip.load()
+    assert lib.ccdm_head_posterior_supported(32, 2, 128, 128, hip.PREC_F16X3) == 1 and lib.ccdm_head_posterior_supported(32, 20, 256, 512, hip.PREC_F16X3) == 0
+    assert lib.ccdm_head_posterior_supported(64, 2, 128, 128, hip.PREC_F16X3) == 0 and lib.ccdm_head_posterior_supported(32, 2, 128, 120, hip.PREC_F16X3) == 0
+
+
 def test_conv_rejects_bad_args(U):
     x = torch.zeros((1, 8, 8, 6), device=U.DEV)
     with pytest.raises(hip.CcdmHipError, match="multiples of 4"):

@@ -53,7 +53,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(hip.SIGNATURES), declared ^ set(hip.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ccdm_version() == hip.ABI_VERSION == 8
+    assert lib.ccdm_version() == hip.ABI_VERSION == 9
     assert ctypes.sizeof(hip.ConvArgs) % 8 == 0 and ctypes.sizeof(hip.PostArgs) % 8 == 0
 
 
@@ -74,6 +74,8 @@ def test_struct_layout_matches_header():
              offsetof(ccdm_resample_args, eps), offsetof(ccdm_resample_args, N), offsetof(ccdm_resample_args, mode), offsetof(ccdm_resample_args, out_raw));
       printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(ccdm_stem_args), offsetof(ccdm_stem_args, K), offsetof(ccdm_stem_args, bias), offsetof(ccdm_stem_args, Cout),
              offsetof(ccdm_stem_args, out), offsetof(ccdm_stem_args, out_slices), sizeof(ccdm_post_run));
+      printf("%zu %zu %zu %zu %zu %zu\n", sizeof(ccdm_head_args), offsetof(ccdm_head_args, slices), offsetof(ccdm_head_args, eps), offsetof(ccdm_head_args, w),
+             offsetof(ccdm_head_args, K), offsetof(ccdm_head_args, logits_out));
       printf("%zu %zu %zu %zu\n", offsetof(ccdm_post_args, run), offsetof(ccdm_post_run, sample_offset), offsetof(ccdm_post_run, noise_row0),
              offsetof(ccdm_post_run, posterior_out));
       return 0; }'''
@@ -82,13 +84,14 @@ def test_struct_layout_matches_header():
         open(os.path.join(d, "t.c"), "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
         out = subprocess.check_output([os.path.join(d, "t")]).decode().split()
-    A, B, R, S = hip.ConvArgs, hip.PostArgs, hip.ResampleArgs, hip.StemArgs
+    A, B, R, S, Hd = hip.ConvArgs, hip.PostArgs, hip.ResampleArgs, hip.StemArgs, hip.HeadArgs
     mine = [ctypes.sizeof(A), A.gamma.offset, A.w.offset, A.emb_row_of_sample.offset, A.out.offset, A.out_slices.offset,
             A.SC1.offset, A.skip_w.offset,
             ctypes.sizeof(B), B.step_table.offset, B.philox_seed.offset, B.xin_stride.offset, B.posterior_out.offset,
             B.noise_row0.offset, B.range_flag.offset,
             ctypes.sizeof(R), R.stats.offset, R.gamma.offset, R.eps.offset, R.N.offset, R.mode.offset, R.out_raw.offset,
             ctypes.sizeof(S), S.K.offset, S.bias.offset, S.Cout.offset, S.out.offset, S.out_slices.offset, hip.POST_RUN_BYTES,
+            ctypes.sizeof(Hd), Hd.slices.offset, Hd.eps.offset, Hd.w.offset, Hd.K.offset, Hd.logits_out.offset,
             B.run.offset, 24, 28, 48]            # ccdm_post_run: noise 0, stride 8, seed 16, sample_offset 24, noise_row0 28, out_probs 32, out_onehot 40, posterior_out 48
     assert [int(v) for v in out] == mine
 
