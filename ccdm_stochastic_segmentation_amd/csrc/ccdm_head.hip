@@ -61,6 +61,12 @@ __global__ __launch_bounds__(256, 3) void k_head(const HeadK k) {
     typedef const __attribute__((address_space(4))) int32_t* cptr_t;
     const int step = k.post.step_ptr ? *(cptr_t)(k.post.step_ptr) : 0;
     const ccdm_post_args post = post_resolve_run(k.post);
+    // the step's coefficients: fetched once per block, ahead of everything (three floats of one table row)
+    float st_al, st_cu, st_mode;
+    {
+        const float* row = post.step_table + (size_t)step * 4;
+        st_al = row[0]; st_cu = row[1]; st_mode = row[2];
+    }
 
     // ---- small loads first: GroupNorm operands, then the weight fragments (2 k-steps x hi|lo, resident), bias / un-scale of this lane's class ----
     GnPrefetch gpf;
@@ -104,7 +110,14 @@ __global__ __launch_bounds__(256, 3) void k_head(const HeadK k) {
     __builtin_amdgcn_sched_barrier(0);
     gn_affine_block(k.gn, n, 0, gpf, reinterpret_cast<f64x2*>(tileb), ab);
     __syncthreads();
-    float2 t0 = ab[4 * q4], t1 = ab[4 * q4 + 1], t2 = ab[4 * q4 + 2], t3 = ab[4 * q4 + 3];
+    // name the block-resident operands here: inside the tile loop the compiler cannot tell these loads from the loop's own prefetch and
+    // would wait for EVERYTHING in flight (vmcnt(0): the next tile's halo request, just issued) at their first use of every tile
+#pragma unroll
+    for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(wh[j]), "+v"(wl[j]));
+#pragma unroll
+    for (int c = 0; c < KP; ++c) asm volatile("" : "+v"(cb[c]), "+v"(cs[c]));
+    asm volatile("" : "+v"(st_al), "+v"(st_cu), "+v"(st_mode));
+    const int smode = (int)st_mode;
     auto commit = [&]() {
         constexpr float PS = ACT_PRESCALE;
         auto silu = [&](const float x) {     // x * sigmoid(x) * PS with v_exp_f32 / v_rcp_f32, as in ccdm_conv.hip
@@ -112,6 +125,7 @@ __global__ __launch_bounds__(256, 3) void k_head(const HeadK k) {
         };
         static_assert(ACT_PRESCALE == 16.0f, "the exp2 bias above is log2(ACT_PRESCALE)");
         int hp = tid >> 3;
+        const float2 t0 = ab[4 * q4], t1 = ab[4 * q4 + 1], t2 = ab[4 * q4 + 2], t3 = ab[4 * q4 + 3];     // (re-read per tile: 8 registers not held across the matrix phase)
 #pragma unroll
         for (int i = 0; i < HD_NITEM; ++i) {
             if (hp < HD_HP) {
@@ -140,8 +154,10 @@ __global__ __launch_bounds__(256, 3) void k_head(const HeadK k) {
     for (int it = 0; it < my_tiles; ++it) {
         const int tile = slice + it * k.slices;
         if (it > 0) __syncthreads();                 // the previous tile's Z values have been gathered
+        // x_t of this thread's output pixel: requested here, consumed behind the matrix phase
+        const size_t opix = px_n + (size_t)((tile / k.tiles_x) * HD_TH + (tid >> 5)) * W + (tile % k.tiles_x) * HD_TW + (tid & 31);
+        const unsigned xtb = post.xt[opix];
         commit();
-        if (it + 1 < my_tiles) request(tile + k.slices);
         __syncthreads();
         f32x16 acc[3];
 #pragma unroll
@@ -172,6 +188,9 @@ __global__ __launch_bounds__(256, 3) void k_head(const HeadK k) {
                 }
             }
         }
+        // the next tile's halo request goes out here: its 44 registers do not have to live beside the three accumulators, and it
+        // flies under the gather, the epilogue arithmetic and the loop-top barrier (three blocks per CU cover the rest)
+        if (it + 1 < my_tiles) request(tile + k.slices);
         __syncthreads();
         // gather + epilogue: thread = output pixel (row tid / 32, column tid % 32 of the tile)
         {
@@ -189,12 +208,13 @@ __global__ __launch_bounds__(256, 3) void k_head(const HeadK k) {
             }
 #pragma unroll
             for (int c = 0; c < KP; ++c) x0[c] = c < K ? fmaf(x0[c], cs[c], cb[c]) : -INFINITY;       // cs is a power of two: exact product
-            const size_t i = px_n + (size_t)(ty * HD_TH + py) * W + tx * HD_TW + pxx;
+            const size_t i = opix;
+            (void)ty; (void)tx;
             if (a.logits_out) {
 #pragma unroll
                 for (int c = 0; c < KP; ++c) if (c < K) a.logits_out[i * K + c] = x0[c];
             }
-            posterior_pixel<KP>(post, i, x0, step);
+            posterior_pixel_core<KP>(post, i, x0, step, st_al, st_cu, smode, (int)xtb);
         }
     }
 }

@@ -39,12 +39,11 @@ __device__ __forceinline__ ccdm_post_args post_resolve_run(const ccdm_post_args&
 
 // pixel i (global index n * HW + pixel) with the head's K values x0[0..K) (logits, or probabilities if !a.softmax; x0[k >= K] = -inf);
 // `a` already resolved by post_resolve_run, `step` = the table row of this denoise step
+// (core: the step's coefficients and the pixel's x_t are handed in, so that a caller may fetch them ahead of time)
 template <int KP>
-__device__ __forceinline__ void posterior_pixel(const ccdm_post_args& a, const size_t i, float (&x0)[KP], const int step) {
+__device__ __forceinline__ void posterior_pixel_core(const ccdm_post_args& a, const size_t i, float (&x0)[KP], const int step, const float al, const float cu,
+                                                     const int mode, const int xt) {
     const int K = a.K;
-    const float* row = a.step_table + (size_t)step * 4;
-    const float al = row[0], cu = row[1];
-    const int mode = (int)row[2];
     if (a.range_flag) {
         // a non-finite head value is how an F16X3 range overflow anywhere upstream surfaces (include/ccdm_hip.h): NaN/Inf
         // survive every conv, GroupNorm and attention on the way here.  (The clamp below would hide it: fmaxf(NaN, 1e-12) = 1e-12.)
@@ -73,7 +72,6 @@ __device__ __forceinline__ void posterior_pixel(const ccdm_post_args& a, const s
         }
         return;
     }
-    const int xt = a.xt[i];
     const float Kf = (float)K;
     const float u = (1.0f - al) / Kf, b = (1.0f - cu) / Kf;
     float A[KP];
@@ -182,6 +180,15 @@ __device__ __forceinline__ void posterior_pixel(const ccdm_post_args& a, const s
         a.xt_next[i] = (uint8_t)bi;
     }
     // CCDM_STEP_LAST_KEEP: x_t is returned unchanged (step_T_sample neither "majority" nor "confidence")
+}
+
+template <int KP>
+__device__ __forceinline__ void posterior_pixel(const ccdm_post_args& a, const size_t i, float (&x0)[KP], const int step) {
+    const float* row = a.step_table + (size_t)step * 4;
+    const float al = row[0], cu = row[1];
+    const int mode = (int)row[2];
+    const int xt = mode == CCDM_STEP_SOFTMAX_ONLY ? 0 : (int)a.xt[i];
+    posterior_pixel_core<KP>(a, i, x0, step, al, cu, mode, xt);
 }
 
 }  // namespace ccdm

@@ -113,6 +113,12 @@ __global__ __launch_bounds__(256) void k_stem(const StemK k) {
             aoff[j][e] = ((tap / 3) * ST_HW + tap % 3) * 16;
         }
     float t1 = 0.f, t2 = 0.f;
+    // name the block-resident operands here: inside the tile loop the compiler cannot tell these loads from the loop's own prefetch and
+    // would wait for everything in flight (vmcnt(0): the next tile's request, just issued) at their first use of every tile
+    float addv = add, wscv = wsc;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) asm volatile("" : "+v"(wh[j]), "+v"(wl[j]));
+    asm volatile("" : "+v"(addv), "+v"(wscv));
 
     if (my_tiles > 0) request(slice);
     for (int it = 0; it < my_tiles; ++it) {
@@ -150,7 +156,7 @@ __global__ __launch_bounds__(256) void k_stem(const StemK k) {
             float* orow = a.out + (px_n + (size_t)oy * W + tx * ST_TW + 4 * g) * a.Cout + co;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float v = fmaf(acc[mi][r], wsc, add);                   // wsc is a power of two: exact product
+                const float v = fmaf(acc[mi][r], wscv, addv);                 // wsc is a power of two: exact product
                 orow[(size_t)((r & 3) + 8 * (r >> 2)) * a.Cout] = v;
                 t1 += v;
                 t2 = fmaf(v, v, t2);
