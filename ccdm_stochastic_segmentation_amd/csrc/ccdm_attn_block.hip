@@ -121,6 +121,11 @@ __global__ __launch_bounds__((T / 32) * 64) void k_qkv_attention(const AttnBlock
         }
     };
     wload(0);
+    // per-thread operands of the tables below, requested now: fetched where they are consumed (behind the statistics barrier) they were a
+    // second full memory round trip in a kernel whose time is one dependent chain
+    const int c_own = min(tid, C - 1), i_own = min(tid, 95);
+    float pf_gamma = a.gamma[c_own], pf_beta = a.beta[c_own];
+    float pf_bias = a.bqkv[96 * hd + i_own], pf_wsq = k.wsq[96 * hd + i_own];
     // ---- tables: GroupNorm affine from the producer's per-channel partial sums; this head's biases and weight un-scales ----
     {
         // per-channel sums over the slices (16 independent loads, not one round trip per partial), exchanged through LDS (the K-row
@@ -132,8 +137,17 @@ __global__ __launch_bounds__((T / 32) * 64) void k_qkv_attention(const AttnBlock
             const char* base = reinterpret_cast<const char*>(a.stats + ((size_t)n * S * C + c) * 2);
             const unsigned stride = (unsigned)C * 16u, last = (unsigned)(S - 1) * stride;
             f64x2 v[16];
+            // (few-pixel producers leave 1-4 slices: 12 of 16 clamped requests would be duplicates — 1 KB per wave each through the vector
+            //  memory front end, ahead of everything else in this kernel's chain; the slice count is uniform: one scalar branch)
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const f64x2*>(base + min((unsigned)u * stride, last));
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f64x2*>(base + min((unsigned)u * stride, last));
+            if (S > 4) {
+#pragma unroll
+                for (int u = 4; u < 16; ++u) v[u] = *reinterpret_cast<const f64x2*>(base + min((unsigned)u * stride, last));
+            } else {
+#pragma unroll
+                for (int u = 4; u < 16; ++u) v[u] = f64x2{0.0, 0.0};
+            }
             f64x2 own = {0.0, 0.0};
 #pragma unroll
             for (int u = 0; u < 16; ++u) { own[0] += u < S ? v[u][0] : 0.0; own[1] += u < S ? v[u][1] : 0.0; }
@@ -148,11 +162,11 @@ __global__ __launch_bounds__((T / 32) * 64) void k_qkv_attention(const AttnBlock
             for (int j = 0; j < cpg; ++j) g += scratch[c_lo + j];
             float meanf, rstd;
             gn_mean_rstd(g[0], g[1], (double)cpg * (double)T, a.eps, meanf, rstd);
-            const float sc = rstd * a.gamma[c];
-            const float sh = a.beta[c] - sc * meanf;
+            const float sc = rstd * (c == tid ? pf_gamma : a.gamma[c]);
+            const float sh = (c == tid ? pf_beta : a.beta[c]) - sc * meanf;
             ab[c] = make_float2(sc * ACT_PRESCALE, sh * ACT_PRESCALE);       // activation pre-scale 2^4, undone through wsq
         }
-        for (int i = tid; i < 96; i += NT) { tb[i] = a.bqkv[96 * hd + i]; tb[96 + i] = k.wsq[96 * hd + i]; }
+        for (int i = tid; i < 96; i += NT) { tb[i] = i == tid ? pf_bias : a.bqkv[96 * hd + i]; tb[96 + i] = i == tid ? pf_wsq : k.wsq[96 * hd + i]; }
     }
     wstore(0);
     wload(1);
