@@ -31,6 +31,97 @@ __global__ __launch_bounds__(256) void k_posterior(const ccdm_post_args a_in) {
     posterior_pixel<KP>(a, i, x0, step);
 }
 
+// Many classes (K > 4): a thread's K head values are K * 4 bytes apart from its neighbour's, and so are the one-hot channels it writes into
+// the stem's input — as per-thread accesses that is K load and K store instructions per wave touching 64 different lines each (K = 20,
+// 16 x 256x512: 289 us, a quarter of the HBM rate, half of it waiting on the memory front end).  Here the block's 256 pixels move as what
+// they are, one contiguous run of 256 * K floats in and 256 * xin_stride floats out: 16-byte requests in lane order, exchanged through LDS
+// (rows padded to an odd pitch: conflict-free per-thread reads).  The stem input's image channels (positions K.. of each pixel) are not
+// touched: a 16-byte piece that lies wholly inside one-hot channels is one store, a piece that straddles image channels is written
+// element by element.  Same arithmetic (posterior_pixel), same bits.
+template <int KP>
+__global__ __launch_bounds__(256) void k_posterior_staged(const ccdm_post_args a_in) {
+    constexpr int PITCH = KP | 1;
+    __shared__ float sx[256 * PITCH];
+    __shared__ int sb[256];
+    const ccdm_post_args a = post_resolve_run(a_in);
+    const size_t npix = (size_t)a.N * a.HW;
+    const size_t i0 = (size_t)blockIdx.x * 256;
+    const int tid = threadIdx.x;
+    const int nvalid = (int)std::min<size_t>(256, npix - i0);
+    const int K = a.K;
+    const int step = a.step_ptr ? *a.step_ptr : 0;
+    // idx / d for idx < 256 * 64, d in [5, 64]: (idx * ceil(2^20 / d)) >> 20 (error < idx / 2^20 < 1 / d)
+    const unsigned hs = (unsigned)a.head_stride;                       // K <= hs <= KP (launch_posterior)
+    const unsigned MK = ((1u << 20) + hs - 1u) / hs;
+    {
+        const float* src = a.head + i0 * hs;
+        const int total = nvalid * (int)hs;
+        if ((total & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+            for (int q = tid; q < total / 4; q += 256) {
+                const f32x4 v = reinterpret_cast<const f32x4*>(src)[q];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned idx = 4u * (unsigned)q + (unsigned)e, p = (idx * MK) >> 20, k = idx - p * hs;
+                    sx[p * PITCH + k] = v[e];
+                }
+            }
+        } else {
+            for (int idx = tid; idx < total; idx += 256) {
+                const unsigned p = ((unsigned)idx * MK) >> 20, k = (unsigned)idx - p * hs;
+                sx[p * PITCH + k] = src[idx];
+            }
+        }
+    }
+    __syncthreads();
+    int bi = 0;
+    if (tid < nvalid) {
+        float x0[KP];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) x0[k] = k < K ? sx[tid * PITCH + k] : -INFINITY;
+        posterior_pixel<KP>(a, i0 + tid, x0, step, &bi);
+    }
+    const int mode = (int)a.step_table[(size_t)step * 4 + 2];          // uniform
+    if (mode != CCDM_STEP_SAMPLE || !a.xin) return;
+    sb[tid] = bi;
+    __syncthreads();
+    {
+        const unsigned stride = (unsigned)a.xin_stride;
+        const unsigned MS = ((1u << 20) + stride - 1u) / stride;
+        float* dst = a.xin + i0 * stride;
+        const int total = nvalid * (int)stride;
+        if ((total & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+            for (int q = tid; q < total / 4; q += 256) {
+                f32x4 v;
+                bool all = true;
+                bool oh[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned idx = 4u * (unsigned)q + (unsigned)e, p = (idx * MS) >> 20, c = idx - p * stride;
+                    oh[e] = c < (unsigned)K;
+                    all = all && oh[e];
+                    v[e] = (int)c == sb[p] ? 1.0f : 0.0f;
+                }
+                if (all) reinterpret_cast<f32x4*>(dst)[q] = v;
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (oh[e]) dst[4 * q + e] = v[e];
+                }
+            }
+        } else {
+            for (int idx = tid; idx < total; idx += 256) {
+                const unsigned p = ((unsigned)idx * MS) >> 20, c = (unsigned)idx - p * stride;
+                if (c < (unsigned)K) dst[idx] = (int)c == sb[p] ? 1.0f : 0.0f;
+            }
+        }
+    }
+}
+
+// the staged form needs contiguous head rows and strides its index arithmetic covers
+static int posterior_kp(int K) { return K <= 2 ? 2 : K <= 4 ? 4 : K <= 8 ? 8 : K <= 16 ? 16 : K <= 20 ? 20 : K <= 24 ? 24 : 32; }
+static bool posterior_staged_ok(const ccdm_post_args& a) {
+    return a.K > 4 && a.head_stride <= posterior_kp(a.K) && (!a.xin || (a.xin_stride >= a.K && a.xin_stride <= 64));
+}
+
 int launch_posterior(const ccdm_post_args& a, hipStream_t s) {
     CCDM_REQUIRE(a.head && a.xt && a.step_table && a.xt_next, "posterior: null pointer");
     CCDM_REQUIRE(a.K >= 2 && a.K <= 32, "posterior: K=%d outside [2,32]", a.K);
@@ -38,6 +129,15 @@ int launch_posterior(const ccdm_post_args& a, hipStream_t s) {
     const size_t npix = (size_t)a.N * a.HW;
     if (!npix) return 0;
     dim3 grid((unsigned)((npix + 255) / 256)), block(256);
+    if (posterior_staged_ok(a)) {
+        if (a.K <= 8) hipLaunchKernelGGL(k_posterior_staged<8>, grid, block, 0, s, a);
+        else if (a.K <= 16) hipLaunchKernelGGL(k_posterior_staged<16>, grid, block, 0, s, a);
+        else if (a.K <= 20) hipLaunchKernelGGL(k_posterior_staged<20>, grid, block, 0, s, a);
+        else if (a.K <= 24) hipLaunchKernelGGL(k_posterior_staged<24>, grid, block, 0, s, a);
+        else hipLaunchKernelGGL(k_posterior_staged<32>, grid, block, 0, s, a);
+        CCDM_CHECK_LAUNCH("posterior");
+        return 0;
+    }
     if (a.K <= 2) hipLaunchKernelGGL(k_posterior<2>, grid, block, 0, s, a);
     else if (a.K <= 4) hipLaunchKernelGGL(k_posterior<4>, grid, block, 0, s, a);
     else if (a.K <= 8) hipLaunchKernelGGL(k_posterior<8>, grid, block, 0, s, a);

@@ -42,7 +42,7 @@ __device__ __forceinline__ ccdm_post_args post_resolve_run(const ccdm_post_args&
 // (core: the step's coefficients and the pixel's x_t are handed in, so that a caller may fetch them ahead of time)
 template <int KP>
 __device__ __forceinline__ void posterior_pixel_core(const ccdm_post_args& a, const size_t i, float (&x0)[KP], const int step, const float al, const float cu,
-                                                     const int mode, const int xt) {
+                                                     const int mode, const int xt, int* const chosen = nullptr) {
     const int K = a.K;
     if (a.range_flag) {
         // a non-finite head value is how an F16X3 range overflow anywhere upstream surfaces (include/ccdm_hip.h): NaN/Inf
@@ -158,7 +158,8 @@ __device__ __forceinline__ void posterior_pixel_core(const ccdm_post_args& a, co
             }
         }
         a.xt_next[i] = (uint8_t)bi;
-        if (a.xin) {
+        if (chosen) *chosen = bi;            // the caller writes the one-hot channels itself (k_posterior_staged)
+        else if (a.xin) {
             float* d = a.xin + i * a.xin_stride;
 #pragma unroll
             for (int k = 0; k < KP; ++k) if (k < K) d[k] = (k == bi) ? 1.0f : 0.0f;
@@ -183,12 +184,12 @@ __device__ __forceinline__ void posterior_pixel_core(const ccdm_post_args& a, co
 }
 
 template <int KP>
-__device__ __forceinline__ void posterior_pixel(const ccdm_post_args& a, const size_t i, float (&x0)[KP], const int step) {
+__device__ __forceinline__ void posterior_pixel(const ccdm_post_args& a, const size_t i, float (&x0)[KP], const int step, int* const chosen = nullptr) {
     const float* row = a.step_table + (size_t)step * 4;
     const float al = row[0], cu = row[1];
     const int mode = (int)row[2];
     const int xt = mode == CCDM_STEP_SOFTMAX_ONLY ? 0 : (int)a.xt[i];
-    posterior_pixel_core<KP>(a, i, x0, step, al, cu, mode, xt);
+    posterior_pixel_core<KP>(a, i, x0, step, al, cu, mode, xt, chosen);
 }
 
 }  // namespace ccdm

@@ -148,22 +148,29 @@ def attention(qkv_ntc: torch.Tensor, heads: int, order: int) -> torch.Tensor:
     return out
 
 
-def posterior_sample(head_nhwk, xt_idx, a, c, mode, *, softmax=True, noise=None, philox_seed=0, sample_offset=0, step=0):
-    """head [N,HW,K] cuda fp32; xt_idx uint8 [N,HW] cuda.  Returns dict of outputs (cpu)."""
+def posterior_sample(head_nhwk, xt_idx, a, c, mode, *, softmax=True, noise=None, philox_seed=0, sample_offset=0, step=0,
+                     head_stride=None, xin_stride=None, xin_fill=0.0):
+    """head [N,HW,K] cuda fp32; xt_idx uint8 [N,HW] cuda.  Returns dict of outputs (cpu).  `head_stride` > K: the K values sit in rows of
+    that many floats (the rest is junk the kernel must not read into its result); `xin_stride` / `xin_fill`: pitch and initial content
+    of the stem input the one-hot is written into (channels >= K must come back untouched)."""
     lib = hip.load()
     N, HW, K = head_nhwk.shape
+    if head_stride is not None and head_stride != K:
+        padded = torch.full((N, HW, head_stride), 1.0e3, device=DEV)
+        padded[..., :K] = head_nhwk
+        head_nhwk = padded
     table = torch.zeros((step + 1, 4), dtype=torch.float32)
     table[step, 0], table[step, 1], table[step, 2] = a, c, float(mode)
     table = table.to(DEV)
     stepbuf = torch.tensor([step], dtype=torch.int32, device=DEV)
     xt_next = torch.full((N, HW), 255, dtype=torch.uint8, device=DEV)
-    xin = torch.zeros((N, HW, (K + 4) // 4 * 4), device=DEV)
+    xin = torch.full((N, HW, xin_stride if xin_stride is not None else (K + 4) // 4 * 4), float(xin_fill), device=DEV)
     probs = torch.zeros((N, HW, K), device=DEV)
     onehot = torch.zeros((N, HW, K), dtype=torch.int64, device=DEV)
     post = torch.zeros((N, HW, K), device=DEV)
     p = hip.PostArgs()
     p.head, p.softmax, p.xt = head_nhwk.data_ptr(), int(softmax), xt_idx.data_ptr()
-    p.head_stride = K
+    p.head_stride = head_nhwk.shape[2]
     p.N, p.HW, p.K = N, HW, K
     p.step_table, p.step_ptr = table.data_ptr(), stepbuf.data_ptr()
     if noise is not None:

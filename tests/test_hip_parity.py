@@ -786,6 +786,34 @@ def test_sampler_bit_exact_on_reference_golden(U, golden, K, parity_log):
         assert diff.mean() <= 2.0 / diff.size + FREE_RUN_FRAC       # (measured 0; a near-tie of the last-ulp normalisation order may flip a pixel)
 
 
+@pytest.mark.parametrize("K,N,HW,xs", [(20, 3, 1000, 23), (20, 2, 512, 24), (5, 3, 333, 8), (7, 2, 700, 7), (9, 1, 257, 12), (21, 2, 300, 24), (32, 2, 513, 35)])
+def test_epilogue_many_classes_moves_whole_pixel_runs(U, K, N, HW, xs):
+    """K > 4: the epilogue stages the block's 256 * K head values and writes the 256 * xin_stride stem-input floats as contiguous 16-byte
+    runs through LDS (k_posterior_staged).  Same bits as the one-thread-per-pixel kernel (reached here by giving the head a row pitch the
+    staged form does not take), over several blocks incl. a ragged last one and pitches that are not multiples of four; the image
+    channels of the stem input (positions >= K) come back untouched; x_t+1 equals the argmax of the written one-hot."""
+    rng = np.random.default_rng(K * 1000 + HW)
+    logits = (rnd(rng, N, HW, K) * 3).to(U.DEV)
+    xt = torch.from_numpy(rng.integers(0, K, (N, HW))).to(torch.uint8).to(U.DEV)
+    _, alphas, cum = O.make_schedule("cosine", 250)
+    a, c = O.posterior_coeffs(alphas, cum, 100)
+    kw = dict(philox_seed=0xFEEDFACE12345678, sample_offset=3, step=2, xin_stride=xs, xin_fill=7.5)
+    staged = U.posterior_sample(logits, xt, a, c, hip.STEP_SAMPLE, **kw)
+    plain = U.posterior_sample(logits, xt, a, c, hip.STEP_SAMPLE, head_stride=40, **kw)
+    for key in ("xt_next", "posterior", "xin"):
+        assert torch.equal(staged[key], plain[key]), key
+    assert torch.equal(staged["xin"][..., :K].argmax(-1), staged["xt_next"].long())
+    assert torch.equal(staged["xin"][..., :K].sum(-1), torch.ones(N, HW))
+    assert torch.equal(staged["xin"][..., K:], torch.full((N, HW, xs - K), 7.5))
+    # host noise instead of the device stream, and the two last-step modes
+    noise = torch.from_numpy(rng.exponential(size=(N, HW, K)).astype(np.float32)).to(U.DEV)
+    for mode in (hip.STEP_SAMPLE, hip.STEP_LAST_CONFIDENCE, hip.STEP_LAST_MAJORITY):
+        s_ = U.posterior_sample(logits, xt, a, c, mode, noise=noise, xin_stride=xs, xin_fill=7.5)
+        p_ = U.posterior_sample(logits, xt, a, c, mode, noise=noise, xin_stride=xs, xin_fill=7.5, head_stride=40)
+        for key in ("xt_next", "posterior", "xin", "probs", "onehot"):
+            assert torch.equal(s_[key], p_[key]), (mode, key)
+
+
 def test_philox_stream_matches_oracle(U):
     """Throughput-mode RNG: the device Philox4x32-10 stream equals the numpy restatement; indices equal
     argmax(P^/E) with the oracle's E wherever the race is not a last-ulp tie."""
