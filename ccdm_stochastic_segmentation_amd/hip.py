@@ -210,6 +210,17 @@ def build(force: bool = False, verbose: bool = False) -> str:
     flavour = hashlib.sha1(" ".join(extra).encode()).hexdigest()[:10] if extra else "default"
     objdir = os.path.join(_HERE, "build", "obj" + ("" if flavour == "default" else "_" + flavour))
     os.makedirs(objdir, exist_ok=True)
+    # prune: objects whose source left the list, and the object directories of flavours other than this one and the default
+    # (the build tree travels to no box, but seventeen stale flavours were 36 MB of it)
+    import shutil
+    wanted = {os.path.basename(s) + ".o" for s in srcs}
+    for f in os.listdir(objdir):
+        if f.endswith(".o") and f not in wanted:
+            os.remove(os.path.join(objdir, f))
+    for d in os.listdir(os.path.dirname(objdir)):
+        p = os.path.join(os.path.dirname(objdir), d)
+        if d.startswith("obj_") and p != objdir and os.path.isdir(p):
+            shutil.rmtree(p, ignore_errors=True)
     stamp = LIB_PATH + ".flavour"
     try:
         linked_flavour = open(stamp).read().strip()
