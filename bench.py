@@ -131,24 +131,37 @@ def cpu_baseline(sd, image4, cfg, cfg_name, seed=0, budget_s=30.0):
 
 
 def self_launch(args) -> int:
-    """`python bench.py --gpus N` without a launcher: start N ranks of this script with torch.distributed.run."""
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script with torch.distributed.run.  The ranks need dmabuf IPC
+    (HSA_ENABLE_IPC_MODE_LEGACY=0, exported on these boxes); where this process had to set it itself and the job fails, the job is
+    started ONCE more without the override, saying so."""
     import socket
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+
+    def launch(env):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        return subprocess.call(cmd, env=env)
+
     env = dict(os.environ)
+    set_here = "HSA_ENABLE_IPC_MODE_LEGACY" not in env
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # the host driver supports dmabuf IPC only (RCCL needs it)
     env["CCDM_BENCH_CHILD"] = "1"
-    return subprocess.call(cmd, env=env)
+    rc = launch(env)
+    if rc != 0 and set_here:
+        print(f"bench.py: the {args.gpus}-rank job failed (rc {rc}) with HSA_ENABLE_IPC_MODE_LEGACY=0 set by bench.py; retrying once without it",
+              file=sys.stderr, flush=True)
+        env.pop("HSA_ENABLE_IPC_MODE_LEGACY")
+        env["CCDM_NO_HSA_IPC_OVERRIDE"] = "1"
+        rc = launch(env)
+    return rc
 
 
 def offline_pmc_traffic(config: str, grid_threads: int):
-    """HBM bytes per launch of the dominant kernel class from the newest committed PMC summary of this config (profiles/r*_pmc_bench_<cfg>.json:
-    rocprofv3 --pmc passes over this same bench command in its single-stream eager form, tools/pmc_bench.sh — FETCH_SIZE / WRITE_SIZE in
-    separate passes, corrected as MI355X_MICROARCH.md prescribes).  Counters cannot be read inside a timed run, so the figure is the
-    off-line one for the same (kernel symbol, grid); None when no summary matches."""
+    """HBM bytes per launch of the dominant kernel class from the newest committed PMC summary of this config (profiles/r*_pmc_bench_<cfg>.json,
+    tools/pmc_bench.sh).  Only the FALLBACK of measure_pmc_traffic: reported under `traffic_offline`, never as `traffic` — it was measured on
+    another visit and another build."""
     import glob
     import re
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
@@ -160,10 +173,76 @@ def offline_pmc_traffic(config: str, grid_threads: int):
             continue
         for key, e in ks.items():
             if "k_conv<1, 16, 3, 1, 8, 32, 4, 2, 1, 1, false, false>" in key and f"grid={grid_threads} " in key and "hbm_bytes" in e:
-                return e["hbm_bytes"], (f"off-line PMC passes over this bench command (single-stream eager form), {os.path.basename(f)}: FETCH_SIZE x 2 (gfx950 wide-read "
-                                        f"correction) + WRITE_SIZE, KiB -> bytes, mean over {e.get('launches')} launches of this (kernel, grid); measured on another visit, "
-                                        "not in this run")
-    return None, None
+                return {"bytes_per_launch": e["hbm_bytes"], "file": os.path.basename(f), "launches": e.get("launches"),
+                        "note": "committed off-line PMC passes over this bench command (another visit, another build): not a measurement of this run"}
+    return None
+
+
+def measure_pmc_traffic(args, grid_threads: int, launches_per_dstep: int, dsteps: int = 8, timeout_s: int = 240):
+    """HBM bytes per launch of the dominant kernel class, measured NOW: two short child passes of this same script under
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes: the two do not fit one, MI355X_MICROARCH.md §rocprofv3 PMC slots;
+    --kernel-trace only beside them), a strided walk of `dsteps` denoise steps of the same workload on ONE stream, eager launches — the form in
+    which a dispatch's counters belong to one kernel.  The class is found in the counter rows themselves: among the conv kernels launched
+    on `grid_threads` threads, the symbol with the largest total duration, and its launch count must equal launches_per_dstep x the
+    denoise steps executed — a stale assumption about the symbol or the tiling gives None, not a wrong number.
+    Units per the guide's HBM section: FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE counts half of the bytes of wide (16 B/lane) coalesced
+    reads on gfx950 -> doubled.  Returns (dict | None, note)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 is not on PATH"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this run is itself being profiled: no nested rocprofv3 passes"
+    executions = 2 * dsteps                                     # --warmup 1 --steps 1
+    tmp = tempfile.mkdtemp(prefix="ccdm_pmc_", dir="/tmp")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(CCDM_BENCH_CHILD="1", TMPDIR="/tmp")
+    per = {}
+    t_all = time.perf_counter()
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+                   "--config", args.config, "--denoise-steps", str(dsteps), "--steps", "1", "--warmup", "1", "--graph", "0", "--substreams", "1",
+                   "--no-cpu-baseline", "--no-secondary", "--prec", args.prec, "--slicing", args.slicing] + (["--batch", str(args.batch)] if args.batch else [])
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                return None, f"the rocprofv3 --pmc {counter} pass did not finish within {timeout_s} s"
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"the rocprofv3 --pmc {counter} pass failed (rc {r.returncode}): {(r.stderr or r.stdout)[-300:]}"
+            rows = {}
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] != counter or "ccdm::k_conv<" not in row["Kernel_Name"] or int(row["Grid_Size"]) != grid_threads:
+                        continue
+                    e = rows.setdefault(row["Kernel_Name"], [0, 0.0, 0.0])
+                    e[0] += 1
+                    e[1] += float(row["Counter_Value"])
+                    e[2] += (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3
+            if not rows:
+                return None, f"no conv kernel on a grid of {grid_threads} threads in the {counter} pass"
+            name = max(rows, key=lambda k: rows[k][2])
+            cnt, tot, us = rows[name]
+            if cnt != launches_per_dstep * executions:
+                return None, (f"{counter} pass: the longest-running conv symbol on that grid was launched {cnt} times, expected {launches_per_dstep} x {executions} "
+                              f"({name[:120]}): the dominant class is not what bench.py assumes")
+            per[counter] = (name, tot / cnt, us / cnt, cnt)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    if per["FETCH_SIZE"][0] != per["WRITE_SIZE"][0]:
+        return None, "the two passes disagree on the dominant symbol"
+    rd, wr = 2.0 * per["FETCH_SIZE"][1] * 1024.0, per["WRITE_SIZE"][1] * 1024.0
+    import re
+    return ({"bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr, "launches_counted": per["FETCH_SIZE"][3],
+             "kernel": re.sub(r"\(.*", "", per["FETCH_SIZE"][0].replace("void ", "")), "avg_launch_us_under_counters": per["FETCH_SIZE"][2],
+             "seconds_spent": time.perf_counter() - t_all},
+            f"measured in this run: two child passes of this bench command under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE ({dsteps}-step strided walk, one "
+            f"stream, eager launches); FETCH_SIZE x 2 (gfx950 wide-read correction) + WRITE_SIZE, KiB -> bytes, mean over the class's launches")
 
 
 def main():
@@ -189,6 +268,11 @@ def main():
     ap.add_argument("--slicing", default="throughput", choices=["throughput", "latency"],
                     help="DenoisingModel.slicing: 'latency' = more, shorter conv workgroups per sample (small batches)")
     ap.add_argument("--per-op", default="", help="write the per-op table of the tapped pass to this file (JSON)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child passes that measure roofline.traffic")
+    ap.add_argument("--digest", action="store_true", help="add the SHA-256 of every rank's last prediction shard to per_rank (tests: a shard of the "
+                                                          "N-rank job equals the same shard sampled alone)")
+    ap.add_argument("--emulate-rank", default="", metavar="R/W", help="one process plays rank R of a W-rank job (its inputs, its Philox sample "
+                                                                     "offset), without a process group: the single-process side of the shard test")
     ap.add_argument("--cpu-probe", type=int, default=0, help=argparse.SUPPRESS)      # child mode of cpu_baseline's all-cores probe
     args = ap.parse_args()
     if args.cpu_probe:
@@ -199,13 +283,17 @@ def main():
         raise SystemExit(self_launch(args))
 
     from ccdm_stochastic_segmentation_amd import build_model, make_synthetic_state_dict, hip
-    from ccdm_stochastic_segmentation_amd.distributed import init_from_env, all_gather_shards
+    from ccdm_stochastic_segmentation_amd.distributed import init_from_env, all_gather_shards, backend_info, barrier as dist_barrier
     from ccdm_stochastic_segmentation_amd.models import auto_substreams
     import torch.distributed as dist
 
     rank, local_rank, world = init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    play_rank, play_world = rank, world
+    if args.emulate_rank:
+        assert world == 1, "--emulate-rank is the single-process side of the shard test"
+        play_rank, play_world = (int(v) for v in args.emulate_rank.split("/"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     dev = torch.device("cuda", local_rank % torch.cuda.device_count())     # (ranks may share a GPU under CCDM_DIST_BACKEND=gloo: tests only)
     torch.cuda.set_device(dev)
@@ -226,7 +314,7 @@ def main():
         model.use_graph = bool(args.graph)
     if args.substreams >= 0:
         model.substreams = args.substreams
-    model.sample_offset = rank * n                                # Philox counters keyed by global sample index
+    model.sample_offset = play_rank * n                           # Philox counters keyed by global sample index
     model.slicing = args.slicing
     use_graph, substreams = bool(model.use_graph), int(model.substreams)
     nsub = substreams if substreams > 0 else auto_substreams(n, cfg["H"], cfg["W"])
@@ -241,7 +329,7 @@ def main():
     feat = None
     if cfg["fce"] is not None:
         feat = torch.from_numpy(rng.standard_normal((n, 384, H // 8, W // 8)).astype(np.float32)).to(dev)
-    x = torch.nn.functional.one_hot(torch.from_numpy(np.random.default_rng(42 + rank).integers(0, K, (n, H, W))), K)
+    x = torch.nn.functional.one_hot(torch.from_numpy(np.random.default_rng(42 + play_rank).integers(0, K, (n, H, W))), K)
     x = x.permute(0, 3, 1, 2).float().to(dev)
     t_arg = {} if not args.denoise_steps else {"t": torch.as_tensor(10000 + args.denoise_steps)}
     n_dsteps = args.denoise_steps or T
@@ -264,23 +352,37 @@ def main():
         one_pass()
 
     # ---- the timed region: exactly `steps` passes of the product path; no taps, no host synchronisation between passes (N = 1) ----
-    if world > 1:
-        dist.barrier()
     torch.cuda.synchronize()
+    if world > 1:
+        dist_barrier()
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = one_pass(timed=world > 1)
-    if world > 1:
-        dist.barrier()
     torch.cuda.synchronize()
+    if world > 1:
+        dist_barrier()
+        torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     per_rank = None
+    digest = None
+    if args.digest:
+        import hashlib
+        lo = play_rank * n if world > 1 else 0                      # (N > 1: `out` is the gathered batch; this rank's shard of it)
+        digest = hashlib.sha256(out[lo:lo + n].contiguous().cpu().numpy().tobytes()).hexdigest()
     if world > 1:
-        mine = torch.tensor([dt, t_gather[0]], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+        # the per-rank record travels as HOST tensors (gloo in the mixed group): pass / gather seconds, device name, shard digest
+        mine = torch.tensor([dt, t_gather[0]], dtype=torch.float64)
         allr = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
-        per_rank = [{"rank": r, "pass_s": float(v[0]) / max(args.steps, 1), "sampling_s": float(v[0] - v[1]) / max(args.steps, 1),
-                     "gather_s": float(v[1]) / max(args.steps, 1)} for r, v in enumerate(allr)]
+        text = json.dumps({"device": torch.cuda.get_device_name(dev), "cuda_device": int(dev.index), "out_sha256": digest}).encode()[:384]
+        blob = torch.zeros(384, dtype=torch.uint8)
+        blob[:len(text)] = torch.frombuffer(bytearray(text), dtype=torch.uint8)
+        blobs = [torch.empty_like(blob) for _ in range(world)]
+        dist.all_gather(blobs, blob)
+        per_rank = [dict({"rank": r, "pass_s": float(v[0]) / max(args.steps, 1), "sampling_s": float(v[0] - v[1]) / max(args.steps, 1),
+                          "gather_s": float(v[1]) / max(args.steps, 1)}, **json.loads(bytes(b.tolist()).rstrip(b"\0").decode()))
+                    for r, (v, b) in enumerate(zip(allr, blobs))]
         dt = max(float(v[0]) for v in allr)
     assert torch.isfinite(out).all()
 
@@ -302,6 +404,11 @@ def main():
         }
         if per_rank is not None:
             res["per_rank"] = per_rank
+            res["distributed"] = backend_info()
+        elif digest is not None:
+            res["out_sha256"] = digest
+        if args.emulate_rank:
+            res["config"]["emulated_rank"] = args.emulate_rank
         step_bytes = (cfg["algo_mb"] * n + cfg["weights_mb"]) * 1e6
         fr = step_bytes / (ms_dstep * 1e-3) / 1e9
         res["roofline_step"] = {"bound": "hbm", "achieved": fr, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fr / HBM_PEAK_GBS,
@@ -311,7 +418,7 @@ def main():
 
     # ---- untimed, rank 0 at N = 1: ONE single-stream eager pass with HIP-event taps on every op (on the engine's stream) -> the dominant
     #      kernel's roofline, the per-stage split, the per-op table; then the single-stream figure of the same product path ----
-    if rank == 0 and not args.no_secondary:
+    def secondary():
         # (N > 1: rank 0 alone, on its own shard, without the gather — the other ranks wait at the final barrier)
         def one_pass():                                            # noqa: F811
             return model(x, image, feat, **t_arg)["diffusion_out"]
@@ -355,11 +462,20 @@ def main():
                 sh["bytes_io"] += o["io_bytes"] * n + o["weight_bytes"]
                 sh["flop"] += o["flop"] * n
                 sh["ops"].append(i)
-            traffic, traffic_src = offline_pmc_traffic(args.config, n * hip.load().ccdm_conv_slices(H, W, 1, 3) * 256) if f16 else (None, None)
+            grid_threads = n * hip.load().ccdm_conv_slices(H, W, 1, 3) * 256
+            traffic = traffic_note = None
+            if f16 and not args.no_pmc:
+                traffic, traffic_note = measure_pmc_traffic(args, grid_threads, len(dom_ops))
+            must_move = bytes_io / len(dom_ops)
             res["roofline"] = {
                 "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "traffic_source": traffic_src or "PMC passes are collected off-line (profiles/): HBM counters cannot be read inside the bench run",
+                "traffic": traffic["bytes_per_launch"] if traffic else None,
+                "traffic_source": traffic_note if traffic else f"not measured in this run ({traffic_note or '--no-pmc'}); see traffic_offline",
+                "traffic_detail": traffic,
+                "traffic_offline": None if traffic else offline_pmc_traffic(args.config, grid_threads),
+                "must_move_bytes_per_launch": must_move,
+                "frac_vs_must_move": (traffic["bytes_per_launch"] / must_move) if traffic else None,
+                "frac_vs_must_move_note": "HBM bytes the counters saw per launch over the bytes that must move (conv input + output + weights, no GroupNorm-read credit)",
                 "note": tap_note,
                 "kernel": f"ccdm::k_conv<F16X3,16,3,1,8,32,4,2,1,1> (<PREC,CK,KS,STRIDE,TH,TW,WAVES,MI,NI,KSP>): every 3x3 stride-1 conv of the {H}x{W} stage "
                           f"(engine ops {dom_ops}), GN+SiLU on load" if f16 else f"ccdm::k_conv<F32,...> every 3x3 stride-1 conv of the {H}x{W} stage (engine ops {dom_ops})",
@@ -424,12 +540,21 @@ def main():
                                 "roofline_step_frac": (cfg["algo_mb"] * n + cfg["weights_mb"]) * 1e6 / (dt1 / n_dsteps) / 1e9 / HBM_PEAK_GBS, "passes": reps,
                                 "note": "same workload on one stream (substreams = 1), same launch mode: secondary figure"}
         model.substreams = substreams
+
+    if rank == 0 and not args.no_secondary:
+        if world == 1:
+            secondary()
+        else:                                                      # the N-rank line must not die on an untimed extra
+            try:
+                secondary()
+            except Exception as e:       # noqa: BLE001
+                res["secondary_error"] = f"{type(e).__name__}: {e}"
     if rank == 0:
         if not args.no_cpu_baseline and world == 1 and args.config in ("c2", "c3shard"):
             res["cpu_baseline"] = cpu_baseline(sd, torch.from_numpy(image_all[:4]), cfg, args.config)
         print(json.dumps(res))
     if world > 1:
-        dist.barrier()
+        dist_barrier()
         dist.destroy_process_group()
 
 

@@ -244,6 +244,14 @@ extern "C" int ccdm_engine_set_epilogue(ccdm_engine* e, const ccdm_post_args* a)
     e->post = *a;
     e->post.step_ptr = e->step;
     e->has_post = true;
+    if (e->run_dev) {
+        // a run block is installed: the kernels read the per-run fields from it, whatever order the two calls came in — keep it
+        // attached and reseed it from the new epilogue (a caller's NULL `run` must not leave set_run updating a block nothing reads)
+        e->post.run = e->run_dev;
+        const ccdm_post_args& p = e->post;
+        e->run = ccdm_post_run{p.noise, p.noise_step_stride, p.philox_seed, p.sample_offset, p.noise_row0, p.out_probs, p.out_onehot, p.posterior_out};
+        e->run_dirty = true;
+    }
     drop_graph(e);
     return 0;
 }

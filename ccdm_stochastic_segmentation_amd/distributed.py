@@ -22,13 +22,25 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     return start, start + base + (1 if rank < rem else 0)
 
 
-def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
-    """(rank, local_rank, world) from torchrun's environment; initialises the process group if world > 1."""
+# what init_from_env brought up: "nccl" (= RCCL; CPU tensors of the same group travel over gloo), "gloo", or None (group made elsewhere)
+_STATE = {"backend": None, "data_via_host": False, "rccl_error": None, "hsa_ipc_legacy_set_here": False}
+
+
+def init_from_env(backend: Optional[str] = None, force: bool = False) -> Tuple[int, int, int]:
+    """(rank, local_rank, world) from torchrun's environment; initialises the process group if world > 1 (or `force`).
+
+    GPU ranks get ONE group with two transports, "cpu:gloo,cuda:nccl": device tensors travel over RCCL / xGMI, host tensors over
+    gloo.  RCCL builds its communicator at the first device collective, so that collective is issued HERE, on one element; if it
+    raises on any rank, every rank learns it over gloo, the RCCL error is printed with the versions and the IPC setting, and the
+    path's one exchange (the final gather) travels through the host instead — loudly (`backend_info()` says so, bench.py puts it
+    in its JSON line): a sampling job whose only collective is one gather should not die because peer-to-peer IPC is unavailable."""
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 and not dist.is_initialized():
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on these hosts (RCCL / shared device tensors)
+    if (world > 1 or force) and not dist.is_initialized():
+        if "HSA_ENABLE_IPC_MODE_LEGACY" not in os.environ and not os.environ.get("CCDM_NO_HSA_IPC_OVERRIDE"):
+            os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"          # dmabuf IPC only on these hosts (RCCL / shared device tensors)
+            _STATE["hsa_ipc_legacy_set_here"] = True
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         if backend is None:
@@ -36,10 +48,64 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
             backend = os.environ.get("CCDM_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
-        elif torch.cuda.is_available():
-            torch.cuda.set_device(local_rank % torch.cuda.device_count())
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            dist.init_process_group(backend="cpu:gloo,cuda:nccl", rank=rank, world_size=world)
+            _STATE["backend"] = "nccl"
+            err = None
+            try:
+                probe = torch.ones(1, device=torch.device("cuda", local_rank))
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+                if int(probe.item()) != world:
+                    err = f"RCCL all_reduce of ones over {world} ranks returned {probe.item()}"
+            except Exception as e:       # noqa: BLE001   (RCCL reports through RuntimeError / DistBackendError)
+                err = f"{type(e).__name__}: {e}"
+            flag = torch.tensor([0 if err is None else 1], dtype=torch.int32)
+            dist.all_reduce(flag)                                    # host tensor: gloo
+            if int(flag.item()) != 0:
+                _STATE["data_via_host"] = True
+                _STATE["rccl_error"] = err or "RCCL failed on another rank"
+                import sys
+                print(f"[ccdm rank {rank}] RCCL did not come up ({_STATE['rccl_error']}); {backend_info()}; "
+                      "the final gather travels through the host (gloo)", file=sys.stderr, flush=True)
+        else:
+            if torch.cuda.is_available():
+                torch.cuda.set_device(local_rank % torch.cuda.device_count())
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            _STATE["backend"] = backend
     return rank, local_rank, world
+
+
+def data_via_host() -> bool:
+    """True when collectives of device tensors must go through host memory: gloo groups (CPU tests, several ranks on one GPU) and
+    the loud fallback of init_from_env."""
+    if _STATE["data_via_host"]:
+        return True
+    b = _STATE["backend"] or (str(dist.get_backend()) if dist.is_initialized() else "gloo")
+    return "nccl" not in b
+
+
+def barrier() -> None:
+    """Barrier over every rank: RCCL's when it carries the data, otherwise a one-element gloo all_reduce (no device involved)."""
+    if not dist.is_initialized():
+        return
+    if data_via_host():
+        dist.all_reduce(torch.zeros(1, dtype=torch.int32))
+    else:
+        dist.barrier(device_ids=[torch.cuda.current_device()])
+
+
+def backend_info() -> dict:
+    """What the N > 1 path runs on — for bench.py's JSON line and the fallback message."""
+    info = {"backend": _STATE["backend"], "data_via_host": bool(_STATE["data_via_host"] or (_STATE["backend"] or "gloo") != "nccl"),
+            "rccl_error": _STATE["rccl_error"], "torch": torch.__version__, "hip": getattr(torch.version, "hip", None),
+            "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+            "HSA_ENABLE_IPC_MODE_LEGACY_set_by": "ccdm" if _STATE["hsa_ipc_legacy_set_here"] else "environment"}
+    try:
+        v = torch.cuda.nccl.version()
+        info["rccl"] = ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+    except Exception:        # noqa: BLE001
+        info["rccl"] = None
+    return info
 
 
 def _check_same_host_rng(world: int, device) -> None:
@@ -69,7 +135,7 @@ def sample_sharded(model, x: torch.Tensor, condition: torch.Tensor, feature_cond
     n = x.shape[0]
     lo, hi = shard_range(n, rank, world)
     if world > 1 and getattr(model, "rng", None) == "torch_cpu":
-        _check_same_host_rng(world, x.device if dist.get_backend() == "nccl" else "cpu")
+        _check_same_host_rng(world, "cpu" if data_via_host() else x.device)
     model.sample_offset = lo
     model.noise_slice = (n, lo)
     try:
@@ -99,7 +165,7 @@ def all_gather_shards(local: torch.Tensor, n: int, world: int, buf: Optional[tor
     m = max(sizes)
     dev = local.device
     pad = local.contiguous()
-    if dist.get_backend() == "gloo" and local.is_cuda:
+    if data_via_host() and local.is_cuda:
         pad = pad.cpu()
     if pad.shape[0] < m:
         pad = torch.cat([pad, pad.new_zeros((m - pad.shape[0],) + tuple(pad.shape[1:]))], 0)

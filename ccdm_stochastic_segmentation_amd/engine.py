@@ -178,12 +178,12 @@ class SamplerEngine:
             args.skip0, args.SC0 = sa.ptr, sa.C
             args.skip1, args.SC1 = (sb.ptr, sb.C) if sb else (0, 0)
             args.skip_w = skip_w.data_ptr()
+        if len(self.op_names) == _TIMELINE_OP:      # diagnostics: phase stamps of one block of this op (-DCCDM_ABLATION library only);
+            args.prec |= 16 << 8                    # set BEFORE the slice query: the bit may change the kernel the layer selects
         # the statistics slices this launch will leave: the library's answer for the fully described layer (the kernel it selects owns the tiling)
         out = self._act(cout, hout, wout, stats, hip.check(self.lib.ccdm_conv_out_slices(C.byref(args)), "conv_out_slices " + wkey))
         args.out = out.ptr
         args.out_stats, args.out_slices = out.stats_ptr, out.slices
-        if len(self.op_names) == _TIMELINE_OP:      # diagnostics: phase stamps of one block of this op (-DCCDM_ABLATION library only)
-            args.prec |= 16 << 8
         hip.check(self.lib.ccdm_engine_add_conv(self._handle, C.byref(args)), "engine_add_conv " + wkey)
         self.op_names.append(wkey)
         # algorithmic work of this launch per SAMPLE (SURVEY 8d accounting: conv io + one GroupNorm statistics read + weights;
@@ -229,6 +229,7 @@ class SamplerEngine:
                                  io_bytes=4 * (cin * self.H * self.W + cout * self.H * self.W), gn_read_bytes=0,
                                  weight_bytes=4 * cout * cin * 9, flop=2 * cin * cout * 9 * self.H * self.W))
         self.stem_onehot_on_load = True
+        self._fold_stats(out)          # (like every other producer: > STATS_MAX_SLICES partials are folded right behind it)
         return out
 
     def _resample(self, x: DevTensor, mode: int, *, gn: Optional[str] = None, act: int = hip.ACT_NONE, want_act: bool, want_raw: bool,

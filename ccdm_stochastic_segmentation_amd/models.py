@@ -305,6 +305,12 @@ class DenoisingModel(nn.Module):
         # "f32" = only repeat the call in fp32 (round-2 behaviour); "raise" = propagate the error
         self.on_range_error = "layers"
         self.f32_layers: set = set()
+        # what the range fallback changed by itself, and for which weights: automatic pins and an automatic switch to fp32 are undone
+        # when the U-Net's parameters change (they describe THOSE weights); `range_events` counts them so a caller can see the mode change
+        self._auto_pins: set = set()
+        self._auto_f32_from: Optional[int] = None           # the precision an unattributable overflow switched away from
+        self._auto_weights_key: Optional[Tuple[int, int]] = None
+        self.range_events = {"overflows": 0, "layers_pinned": 0, "switched_to_f32": 0, "reset_on_new_weights": 0}
         self._range_probe: Optional[Dict[str, float]] = None        # filled while a diagnosing fp32 re-run is under way
         # workgroup slicing of the conv kernels: "throughput" (default) = the batch-size-independent rule — samples do not depend on how
         # a batch is sharded over ranks or sub-batches, bit for bit; "latency" = up to 32 one- or two-tile workgroups per sample
@@ -412,11 +418,19 @@ class DenoisingModel(nn.Module):
         if self.on_range_error not in ("layers", "f32", "raise"):
             raise ValueError(f"on_range_error: {self.on_range_error!r} (expected 'layers', 'f32' or 'raise')")
         state = torch.get_rng_state() if self.rng == "torch_cpu" else None
+        if self._auto_weights_key is not None and self._auto_weights_key != self._weights_key():
+            # new weights: what the fallback learned about the old ones (pins, the switch to fp32) no longer applies
+            self.f32_layers -= self._auto_pins
+            if self._auto_f32_from is not None and self.prec == hip.PREC_F32:
+                self.prec = self._auto_f32_from
+            self._auto_pins, self._auto_f32_from, self._auto_weights_key = set(), None, None
+            self.range_events["reset_on_new_weights"] += 1
         try:
             return fn()
         except hip.CcdmRangeError as e:
             if self.prec == hip.PREC_F32 or self.on_range_error == "raise":
                 raise
+            self.range_events["overflows"] += 1
             LOGGER.warning("%s -- repeating this call with the exact-fp32 kernels", e)
             if state is not None:
                 torch.set_rng_state(state)
@@ -435,6 +449,9 @@ class DenoisingModel(nn.Module):
                 new = [k for k in hot if k not in self.f32_layers]
                 if new:
                     self.f32_layers.update(new)
+                    self._auto_pins.update(new)
+                    self._auto_weights_key = self._weights_key()
+                    self.range_events["layers_pinned"] += len(new)
                     LOGGER.warning("F16X3 range: %d layer(s) stage values beyond %.0f (%s ...); they run the exact-fp32 kernels from now on "
                                    "(DenoisingModel.f32_layers)", len(new), limit, ", ".join(new[:4]))
                     # the engines built for the old pin set and the diagnosing all-fp32 ones are dead weight now — at Cityscapes-sized
@@ -444,8 +461,10 @@ class DenoisingModel(nn.Module):
                     # an overflow the probe cannot attribute to a pinnable layer (every step of this call was looked at): without a
                     # new pin every later call would run F16X3, overflow and be repeated in fp32 — about 5x the cost, forever
                     LOGGER.warning("F16X3 range: the overflow could not be attributed to a layer (largest staged value %.3g); this model "
-                                   "runs the exact-fp32 kernels from now on (DenoisingModel.prec = PREC_F32)",
+                                   "runs the exact-fp32 kernels until its weights change (DenoisingModel.prec = PREC_F32; range_events counts it)",
                                    max(probe.values()) if probe else float("nan"))
+                    self._auto_f32_from, self._auto_weights_key = prec, self._weights_key()
+                    self.range_events["switched_to_f32"] += 1
                     self.prec = hip.PREC_F32
                     self._engines = {k: v for k, v in self._engines.items() if k[6] == hip.PREC_F32}
             return out

@@ -452,6 +452,25 @@ def test_bench_self_launch_command(monkeypatch):
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 
 
+def test_bench_self_launch_retries_once_without_its_own_ipc_override(monkeypatch):
+    """Where bench.py itself had to set HSA_ENABLE_IPC_MODE_LEGACY=0 and the N-rank job fails, it is started once more without the
+    override; an override that came from the environment is never removed."""
+    import bench
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    for preset, want in ((None, ["0", None]), ("0", ["0"])):
+        envs = []
+        monkeypatch.setattr(bench.subprocess, "call", lambda cmd, env=None: envs.append(env.get("HSA_ENABLE_IPC_MODE_LEGACY")) or 7)
+        if preset is None:
+            monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY", raising=False)
+        else:
+            monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", preset)
+        with pytest.raises(SystemExit) as e:
+            bench.main()
+        assert e.value.code == 7 and envs == want, (preset, envs)
+
+
 def test_host_noise_is_drawn_in_bounded_blocks(monkeypatch):
     """rng='torch_cpu': the per-step Exp(1) draws are consumed from torch's generator in the reference's order whatever the block
     size, and no more than one block is resident (checked on the host logic with a stub engine)."""

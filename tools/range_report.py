@@ -44,22 +44,11 @@ def main():
         source = "synthetic weights (make_synthetic_state_dict seed 0)"
     dev = torch.device("cuda:0")
     model = model.to(dev).eval()
-    model.prec = hip.PREC_F32
-    rng = np.random.default_rng(7)
     n = args.batch
-    image = torch.from_numpy((rng.uniform(-1, 1, (n, C_img, H, W)) if cfg["image"] == "uniform" else rng.standard_normal((n, C_img, H, W))).astype(np.float32)).to(dev)
-    feat = torch.from_numpy(rng.standard_normal((n, 384, H // 8, W // 8)).astype(np.float32)).to(dev) if cfg["fce"] else None
-    model._range_probe = {}
-    t_list = sorted({T, (3 * T) // 4, T // 2, T // 4, 2, 1}, reverse=True)
-    for t in t_list:
-        x = torch.nn.functional.one_hot(torch.from_numpy(rng.integers(0, K, (n, H, W))), K).permute(0, 3, 1, 2).float().to(dev)
-        model(x, image, feat, t=torch.full((n,), float(t)), validation=True)
-    probe = model._collect_probe()
-    model._range_probe = None
-    rows = sorted(({"layer": k, "max_staged_abs": v, "headroom": (hip.F16X3_LIMIT / v if v > 0 else float("inf"))} for k, v in probe.items()),
-                  key=lambda r: r["headroom"])
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from verify_checkpoint import measure_ranges       # the measurement itself (shared with tools/verify_checkpoint.py)
+    rows, pinned, t_list = measure_ranges(model, cfg, n, seed=7)
     limit = hip.F16X3_LIMIT * model.RANGE_MARGIN
-    pinned = [r["layer"] for r in rows if not (r["max_staged_abs"] < limit)]
     res = {"config": args.config, "weights": source, "timesteps": t_list, "batch": n, "limit": hip.F16X3_LIMIT, "pin_threshold": limit,
            "layers_within_margin": pinned, "min_headroom": rows[0]["headroom"] if rows else None, "layers": rows}
     print(f"{len(rows)} conv layers, weights: {source}; smallest headroom x{rows[0]['headroom']:.1f} ({rows[0]['layer']}: max |a| = {rows[0]['max_staged_abs']:.3g})")
