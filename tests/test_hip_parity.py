@@ -2035,13 +2035,14 @@ def test_graph_survives_a_new_philox_key_and_new_noise_blocks(U):
     try:
         torch.manual_seed(11)
         whole = model(x, image, t=t)["diffusion_out"].clone()
+        captures = eng.graph_captures()         # 2: re-installing the epilogue above dropped the first graph (the op list may have changed)
         M.HOST_NOISE_BLOCK_BYTES = 1
         torch.manual_seed(11)
         blocks = model(x, image, t=t)["diffusion_out"].clone()
     finally:
         M.HOST_NOISE_BLOCK_BYTES = old
     assert torch.equal(whole, blocks)
-    assert eng.graph_captures() == 1
+    assert captures == 2 and eng.graph_captures() == captures      # a new noise buffer per block re-captures nothing
 
 
 # ------------------------------------------------------------------------------------------ A14 variants
