@@ -116,6 +116,123 @@ __global__ __launch_bounds__(256) void k_posterior_staged(const ccdm_post_args a
     }
 }
 
+// More than 32 classes (round 5; no reference dataset has them — builder.py:36-45 accepts any label shape): a pixel's K values live in
+// an LDS row of the block instead of registers and every pass over the classes is a run-time loop — the arithmetic, its order
+// (k ascending; the normalising sum in 16-blocks, then the tail, then tail + blocks) and the Philox counters are posterior_pixel_core's,
+// statement for statement (tested bit for bit against the register kernels at K <= 32, against the reference's own draws at K = 40).
+// 128 pixels per block, row pitch K | 1 floats (conflict-free per-thread walks): K <= 255 (x_t is a uint8 class index).
+__global__ __launch_bounds__(128) void k_posterior_many(const ccdm_post_args a_in) {
+    extern __shared__ float smany[];
+    const ccdm_post_args a = post_resolve_run(a_in);
+    const int K = a.K, PITCH = K | 1;
+    const size_t npix = (size_t)a.N * a.HW;
+    const size_t i0 = (size_t)blockIdx.x * 128;
+    const int tid = threadIdx.x;
+    const int nvalid = (int)std::min<size_t>(128, npix - i0);
+    const int step = a.step_ptr ? *a.step_ptr : 0;
+    {   // the block's head values: one contiguous run when the head rows are dense, in lane order either way
+        const unsigned hs = (unsigned)a.head_stride;
+        const float* src = a.head + i0 * hs;
+        const int total = nvalid * K;
+        for (int idx = tid; idx < total; idx += 128) {
+            const unsigned p = (unsigned)idx / (unsigned)K, k = (unsigned)idx - p * (unsigned)K;
+            smany[p * PITCH + k] = src[(size_t)p * hs + k];
+        }
+    }
+    __syncthreads();
+    const float* trow = a.step_table + (size_t)step * 4;
+    const float al = trow[0], cu = trow[1];
+    const int mode = (int)trow[2];
+    int bi = -1;
+    if (tid < nvalid) {
+        float* x = smany + tid * PITCH;
+        const size_t i = i0 + tid;
+        const int xt = mode == CCDM_STEP_SOFTMAX_ONLY ? 0 : (int)a.xt[i];
+        if (a.range_flag) {
+            float chk = 0.f;
+            for (int k = 0; k < K; ++k) chk += fabsf(x[k]);
+            if (!(chk <= 3.0e38f)) *a.range_flag = 1;
+        }
+        if (a.softmax & 1) {
+            float mx = x[0];
+            for (int k = 1; k < K; ++k) mx = fmaxf(mx, x[k]);
+            float sum = 0.f;
+            for (int k = 0; k < K; ++k) { x[k] = expf(x[k] - mx); sum += x[k]; }
+            for (int k = 0; k < K; ++k) x[k] = x[k] / sum;
+        }
+        if (mode == CCDM_STEP_SOFTMAX_ONLY) {
+            if (a.out_probs) for (int k = 0; k < K; ++k) a.out_probs[i * K + k] = x[k];
+        } else {
+            const float Kf = (float)K;
+            const float u = (1.0f - al) / Kf, b = (1.0f - cu) / Kf;
+            auto Ak = [&](const int k) { return (k == xt ? al : 0.0f) + u; };
+            float S = Ak(0);
+            for (int k = 1; k < K; ++k) S = S + Ak(k);
+            const float bS = b * S;
+            float R = 0.f;
+            for (int k = 0; k < K; ++k) {
+                const float rk = x[k] / (cu * Ak(k) + bS);
+                x[k] = rk;
+                R = k == 0 ? rk : R + rk;
+            }
+            const float bR = b * R;
+            for (int k = 0; k < K; ++k) x[k] = fmaxf(Ak(k) * (cu * x[k] + bR), 1e-12f);
+            float tot;
+            {
+                const int full = (K / 16) * 16;
+                float hi = 0.f, tail = 0.f;
+                for (int s0 = 0; s0 < full; s0 += 16) {
+                    float blk = x[s0];
+                    for (int k = 1; k < 16; ++k) blk = blk + x[s0 + k];
+                    hi = s0 == 0 ? blk : hi + blk;
+                }
+                for (int k = full; k < K; ++k) tail = k == full ? x[k] : tail + x[k];
+                tot = full < K ? (full > 0 ? tail + hi : tail) : hi;
+            }
+            for (int k = 0; k < K; ++k) x[k] = x[k] / tot;
+            if (a.posterior_out) for (int k = 0; k < K; ++k) a.posterior_out[i * K + k] = x[k];
+            if (mode == CCDM_STEP_SAMPLE) {
+                float best = -INFINITY;
+                bi = 0;
+                if (a.noise) {
+                    const float* e = a.noise + (size_t)(step - a.noise_row0) * a.noise_step_stride + i * K;
+                    for (int k = 0; k < K; ++k) {
+                        const float qv = x[k] / e[k];
+                        if (qv > best) { best = qv; bi = k; }
+                    }
+                } else {
+                    const uint32_t pix = (uint32_t)(i % a.HW), smp = (uint32_t)(i / a.HW) + a.sample_offset;
+                    const uint32_t k0 = (uint32_t)a.philox_seed, k1 = (uint32_t)(a.philox_seed >> 32);
+                    for (int kq = 0; kq * 4 < K; ++kq) {
+                        uint32_t w[4];
+                        Philox::run(pix, smp, (uint32_t)step, (uint32_t)kq, k0, k1, w);
+                        for (int j = 0; j < 4; ++j) {
+                            const int k = kq * 4 + j;
+                            if (k < K) {
+                                const float qv = x[k] / u32_to_exp1(w[j]);
+                                if (qv > best) { best = qv; bi = k; }
+                            }
+                        }
+                    }
+                }
+                a.xt_next[i] = (uint8_t)bi;
+                if (a.xin) {
+                    float* d = a.xin + i * a.xin_stride;
+                    for (int k = 0; k < K; ++k) d[k] = (k == bi) ? 1.0f : 0.0f;
+                }
+            } else if (mode == CCDM_STEP_LAST_CONFIDENCE) {
+                if (a.out_probs) for (int k = 0; k < K; ++k) a.out_probs[i * K + k] = x[k];
+            } else if (mode == CCDM_STEP_LAST_MAJORITY) {
+                float best = x[0];
+                bi = 0;
+                for (int k = 1; k < K; ++k) if (x[k] > best) { best = x[k]; bi = k; }
+                if (a.out_onehot) for (int k = 0; k < K; ++k) a.out_onehot[i * K + k] = (k == bi) ? 1 : 0;
+                a.xt_next[i] = (uint8_t)bi;
+            }
+        }
+    }
+}
+
 // the staged form needs contiguous head rows and strides its index arithmetic covers
 static int posterior_kp(int K) { return K <= 2 ? 2 : K <= 4 ? 4 : K <= 8 ? 8 : K <= 16 ? 16 : K <= 20 ? 20 : K <= 24 ? 24 : 32; }
 static bool posterior_staged_ok(const ccdm_post_args& a) {
@@ -124,10 +241,18 @@ static bool posterior_staged_ok(const ccdm_post_args& a) {
 
 int launch_posterior(const ccdm_post_args& a, hipStream_t s) {
     CCDM_REQUIRE(a.head && a.xt && a.step_table && a.xt_next, "posterior: null pointer");
-    CCDM_REQUIRE(a.K >= 2 && a.K <= 32, "posterior: K=%d outside [2,32]", a.K);
+    CCDM_REQUIRE(a.K >= 2 && a.K <= CCDM_MAX_CLASSES, "posterior: K=%d outside [2,%d]", a.K, CCDM_MAX_CLASSES);
     CCDM_REQUIRE(a.head_stride >= a.K, "posterior: head_stride %d < K %d", a.head_stride, a.K);
     const size_t npix = (size_t)a.N * a.HW;
     if (!npix) return 0;
+    if (a.K > 32 || (a.softmax & CCDM_POST_DIAG_MANY)) {       // LDS-resident classes, run-time loops (any K; the diagnostic bit: parity tests at K <= 32)
+        const size_t lds = (size_t)128 * (a.K | 1) * sizeof(float);
+        if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k_posterior_many), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return fail("posterior: cannot reserve %zu bytes of LDS for K=%d", lds, a.K);
+        hipLaunchKernelGGL(k_posterior_many, dim3((unsigned)((npix + 127) / 128)), dim3(128), lds, s, a);
+        CCDM_CHECK_LAUNCH("posterior(many classes)");
+        return 0;
+    }
     dim3 grid((unsigned)((npix + 255) / 256)), block(256);
     if (posterior_staged_ok(a)) {
         if (a.K <= 8) hipLaunchKernelGGL(k_posterior_staged<8>, grid, block, 0, s, a);

@@ -34,7 +34,9 @@ STEP_SAMPLE, STEP_LAST_CONFIDENCE, STEP_LAST_MAJORITY, STEP_LAST_KEEP, STEP_SOFT
 STATS_MAX_SLICES = 64       # CCDM_STATS_MAX_SLICES: what a GroupNorm consumer reads
 F16X3_LIMIT = 4094.0        # CCDM_F16X3_LIMIT: the fp16 split is exact for staged |a| below this
 STATS_FOLD_SLICES = 16      # CCDM_STATS_FOLD_SLICES: what the engine folds a larger slice count to
-ABI_VERSION = 9          # CCDM_ABI_VERSION of include/ccdm_hip.h
+ABI_VERSION = 10         # CCDM_ABI_VERSION of include/ccdm_hip.h
+MAX_CLASSES = 255        # CCDM_MAX_CLASSES: x_t is a uint8 class index (K <= 32 in registers, more through LDS rows)
+POST_DIAG_MANY = 256     # CCDM_POST_DIAG_MANY: OR into PostArgs.softmax to run the many-class epilogue kernel at any K (parity tests)
 
 
 class ConvArgs(C.Structure):

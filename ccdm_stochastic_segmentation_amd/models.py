@@ -609,10 +609,10 @@ def build_model(
     img_shape, label_shape = input_shapes
     img_channels = img_shape[0]
     num_classes = label_shape[0]
-    if not 2 <= num_classes <= 32:
-        # the posterior / sampling kernel keeps a pixel's K values in registers (ccdm_sampler.hip, instantiated up to 32); the reference's
-        # datasets have 2 (LIDC) and 20 (Cityscapes) classes
-        raise ValueError(f"label shape {tuple(label_shape)}: {num_classes} classes, the HIP sampler is built for 2..32 (DESIGN.md section 8)")
+    if not 2 <= num_classes <= hip.MAX_CLASSES:
+        # x_t travels as a uint8 class index; up to 32 classes a pixel's K values stay in registers, more go through LDS rows
+        # (ccdm_sampler.hip: k_posterior_many).  The reference's datasets have 2 (LIDC) and 20 (Cityscapes) classes.
+        raise ValueError(f"label shape {tuple(label_shape)}: {num_classes} classes, the HIP sampler is built for 2..{hip.MAX_CLASSES} (DESIGN.md section 8)")
     diffusion = DiffusionModel(schedule, time_steps, num_classes, schedule_params=schedule_params)
     if backbone == "unet_openai":
         spec = make_unet_spec(

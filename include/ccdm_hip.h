@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define CCDM_ABI_VERSION 9
+#define CCDM_ABI_VERSION 10
 #define CCDM_MAX_CHANNELS 1024      /* max C0+C1 of a GroupNorm'ed conv input */
 #define CCDM_STATS_MAX_SLICES 64    /* partial-statistics slices per sample a GroupNorm consumer reads (more: ccdm_stats_fold) */
 #define CCDM_STATS_FOLD_SLICES 16   /* what ccdm_stats_fold reduces a larger slice count to */
@@ -254,9 +254,11 @@ typedef struct ccdm_post_run {
     float* out_probs; int64_t* out_onehot; float* posterior_out;
 } ccdm_post_run;
 
+#define CCDM_MAX_CLASSES 255        /* x_t is a uint8 class index; K <= 32 keeps a pixel's classes in registers, more go through LDS rows */
+#define CCDM_POST_DIAG_MANY 256     /* diagnostic bit of ccdm_post_args.softmax: run the many-class (LDS-row) kernel at any K (parity tests) */
 typedef struct ccdm_post_args {
     const float* head;           /* dev [N,HW,head_stride] head conv output (logits, or probabilities if !softmax), first K channels used */
-    int32_t softmax;             /* 1: apply softmax over K first */
+    int32_t softmax;             /* bit 0: apply softmax over K first (| CCDM_POST_DIAG_MANY) */
     int32_t head_stride;         /* floats per pixel of `head` (>= K; the head conv pads K up to a multiple of 4) */
     const uint8_t* xt;           /* dev [N,HW] class index of x_t */
     int32_t N, HW, K;

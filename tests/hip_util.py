@@ -149,7 +149,7 @@ def attention(qkv_ntc: torch.Tensor, heads: int, order: int) -> torch.Tensor:
 
 
 def posterior_sample(head_nhwk, xt_idx, a, c, mode, *, softmax=True, noise=None, philox_seed=0, sample_offset=0, step=0,
-                     head_stride=None, xin_stride=None, xin_fill=0.0):
+                     head_stride=None, xin_stride=None, xin_fill=0.0, many=False):
     """head [N,HW,K] cuda fp32; xt_idx uint8 [N,HW] cuda.  Returns dict of outputs (cpu).  `head_stride` > K: the K values sit in rows of
     that many floats (the rest is junk the kernel must not read into its result); `xin_stride` / `xin_fill`: pitch and initial content
     of the stem input the one-hot is written into (channels >= K must come back untouched)."""
@@ -169,7 +169,7 @@ def posterior_sample(head_nhwk, xt_idx, a, c, mode, *, softmax=True, noise=None,
     onehot = torch.zeros((N, HW, K), dtype=torch.int64, device=DEV)
     post = torch.zeros((N, HW, K), device=DEV)
     p = hip.PostArgs()
-    p.head, p.softmax, p.xt = head_nhwk.data_ptr(), int(softmax), xt_idx.data_ptr()
+    p.head, p.softmax, p.xt = head_nhwk.data_ptr(), int(softmax) | (hip.POST_DIAG_MANY if many else 0), xt_idx.data_ptr()       # many: the LDS-row kernel at any K
     p.head_stride = head_nhwk.shape[2]
     p.N, p.HW, p.K = N, HW, K
     p.step_table, p.step_ptr = table.data_ptr(), stepbuf.data_ptr()

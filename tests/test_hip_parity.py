@@ -852,6 +852,128 @@ def test_epilogue_many_classes_moves_whole_pixel_runs(U, K, N, HW, xs):
         check_epilogue_against_oracle(s_, logits, xt, a, c, noise, mode, K)
 
 
+@pytest.mark.parametrize("K,N,HW,xs", [(2, 2, 300, 4), (5, 3, 333, 8), (20, 2, 512, 24), (32, 2, 513, 35)])
+def test_epilogue_lds_rows_equal_the_register_kernels(U, K, N, HW, xs):
+    """k_posterior_many (the kernel more than 32 classes run: a pixel's classes in an LDS row, run-time loops) against the register
+    kernels at class counts both can take: every output identical, bit for bit, in every step mode, with the device Philox stream and
+    with host noise, softmax on and off — the arithmetic and its order are one definition written twice."""
+    rng = np.random.default_rng(K * 77 + HW)
+    logits = (rnd(rng, N, HW, K) * 3).to(U.DEV)
+    xt = torch.from_numpy(rng.integers(0, K, (N, HW))).to(torch.uint8).to(U.DEV)
+    _, alphas, cum = O.make_schedule("cosine", 250)
+    a, c = O.posterior_coeffs(alphas, cum, 100)
+    noise = torch.from_numpy(rng.exponential(size=(N, HW, K)).astype(np.float32)).to(U.DEV)
+    probs_in = torch.softmax(logits, -1)
+    for mode in (hip.STEP_SAMPLE, hip.STEP_LAST_CONFIDENCE, hip.STEP_LAST_MAJORITY, hip.STEP_SOFTMAX_ONLY):
+        for kw in (dict(philox_seed=0xFEEDFACE12345678, sample_offset=3, step=2), dict(noise=noise)):
+            for head, sm in ((logits, True), (probs_in, False)):
+                r_ = U.posterior_sample(head, xt, a, c, mode, softmax=sm, xin_stride=xs, xin_fill=7.5, **kw)
+                m_ = U.posterior_sample(head, xt, a, c, mode, softmax=sm, xin_stride=xs, xin_fill=7.5, many=True, **kw)
+                for key in ("xt_next", "posterior", "xin", "probs", "onehot"):
+                    assert torch.equal(r_[key], m_[key]), (mode, sm, key)
+
+
+@pytest.mark.parametrize("K", [33, 40, 100, 255])
+def test_epilogue_more_than_32_classes_against_the_oracle(U, K):
+    """K > 32 (k_posterior_many): posterior, clamp, normalisation and the Exp(1) race against the oracle's restatement of the reference's
+    forms, every step mode; ragged block counts; the stem input's image channels untouched."""
+    N, HW = 2, 333
+    rng = np.random.default_rng(K)
+    logits = (rnd(rng, N, HW, K) * 3).to(U.DEV)
+    xt = torch.from_numpy(rng.integers(0, K, (N, HW))).to(torch.uint8).to(U.DEV)
+    _, alphas, cum = O.make_schedule("cosine", 250)
+    a, c = O.posterior_coeffs(alphas, cum, 100)
+    noise = torch.from_numpy(rng.exponential(size=(N, HW, K)).astype(np.float32)).to(U.DEV)
+    xs = (K + 3 + 3) // 4 * 4
+    for mode in (hip.STEP_SAMPLE, hip.STEP_LAST_CONFIDENCE, hip.STEP_LAST_MAJORITY):
+        r = U.posterior_sample(logits, xt, a, c, mode, noise=noise, xin_stride=xs, xin_fill=7.5)
+        check_epilogue_against_oracle(r, logits, xt, a, c, noise, mode, K)
+        assert torch.equal(r["xin"][..., K:], torch.full((N, HW, xs - K), 7.5))
+        if mode == hip.STEP_SAMPLE:
+            assert torch.equal(r["xin"][..., :K].argmax(-1), r["xt_next"].long()) and torch.equal(r["xin"][..., :K].sum(-1), torch.ones(N, HW))
+    # device stream: same sample_offset, same draws (sharding invariance); the stream is the numpy restatement's
+    r1 = U.posterior_sample(logits, xt, a, c, hip.STEP_SAMPLE, philox_seed=0x1234567890ABCDEF, sample_offset=5, step=3)
+    r2 = U.posterior_sample(logits[1:].contiguous(), xt[1:].contiguous(), a, c, hip.STEP_SAMPLE, philox_seed=0x1234567890ABCDEF, sample_offset=6, step=3)
+    assert torch.equal(r2["xt_next"], r1["xt_next"][1:])
+    e = torch.from_numpy(O.philox_exponential(0x1234567890ABCDEF, 3, 5, N, HW, K))
+    q = r1["posterior"] / e
+    top2 = torch.topk(q, 2, -1).values
+    clear = (top2[..., 0] - top2[..., 1]) > 1e-5 * top2[..., 0]
+    assert clear.float().mean() > 0.98 and torch.equal(q.argmax(-1)[clear], r1["xt_next"].long()[clear])
+
+
+def test_forty_classes_against_the_reference(U, golden, parity_log):
+    """G18 (tools/gen_goldens_k40.py): the REFERENCE at K = 40 — its O(K^2) posterior, its sampler given the noise torch drew, and a seeded
+    6-step strided walk of a 40-class network (teacher-forced network outputs and draws; free-running with the parity RNG)."""
+    from tests.test_oracle_golden import k40_case
+    g = golden["g18_k40"]
+    K = 40
+    _, alphas, cum = O.make_schedule("cosine", 250, {"s": 0.008})
+    xt = torch.from_numpy(g["post_xt"].astype(np.int64))
+    x0 = torch.from_numpy(g["post_x0"])
+    N, _, H, W = x0.shape
+    for t in (250, 125, 2, 1):
+        a, c = O.posterior_coeffs(alphas, cum, t)
+        r = U.posterior_sample(U.nhwc(x0).reshape(N, H * W, K), xt.to(torch.uint8).reshape(N, -1).to(U.DEV), a, c, hip.STEP_LAST_CONFIDENCE, softmax=False)
+        ref = O.normalise_probs(torch.clamp(torch.from_numpy(g[f"post_t{t}"]), min=1e-12))
+        np.testing.assert_allclose(r["probs"].reshape(N, H, W, K).numpy(), ref.numpy(), rtol=0, atol=3e-6)
+    probs, noise = torch.from_numpy(g["smp_probs"]), torch.from_numpy(g["smp_noise"])
+    N, _, H, W = probs.shape
+    r = U.posterior_sample(U.nhwc(probs).reshape(N, H * W, K), torch.zeros((N, H * W), dtype=torch.uint8, device=U.DEV), 0.0, 1.0, hip.STEP_SAMPLE,
+                           softmax=False, noise=noise.to(U.DEV))
+    ph = r["posterior"].reshape(N, H, W, K)
+    np.testing.assert_allclose(ph.numpy(), g["smp_phat"], rtol=4e-7, atol=0)
+    idx = torch.argmax(ph / noise.reshape(N, H, W, K), -1)
+    assert torch.equal(idx, r["xt_next"].reshape(N, H, W).long())
+    diff = idx.numpy() != g["smp_idx"]
+    parity_log("g18_k40", sampler_index_mismatch_vs_reference=diff.mean(), pixels=diff.size)
+    assert diff.mean() <= 2.0 / diff.size + FREE_RUN_FRAC
+    # the walk
+    _, sd, img = k40_case()
+    model = build_model(250, "cosine", {"s": 0.008}, [(3, 32, 32), (K, 32, 32)], (3, 32, 32), "unet_openai",
+                        dict(LIDC_BP, channel_mult=[1, 2, 4], attention_resolutions=[8]), "datasets.cityscapes", "confidence", None)
+    model.unet.load_state_dict(sd, strict=True)
+    model = model.to("cuda:0").eval()
+    N, H, W = 2, 32, 32
+    t_values = [int(t) for t in g["walk_t_values"]]
+    torch.manual_seed(7)
+    if not np.array_equal(torch.empty(64).exponential_(1).numpy(), golden["g6_sampler"]["exp_stream_seed7"]):
+        pytest.fail(f"torch {torch.__version__}: this host's CPU exponential_(1) stream differs from the fixture host's")
+    sched = O.make_schedule("cosine", 250, {"s": 0.008})
+    torch.manual_seed(42)
+    xT, _ = O.draw_x_T(N, K, H, W)
+    assert np.array_equal(xT.numpy(), g["walk_xT"])
+    worst, flips = 0.0, 0.0
+    for j, t in enumerate(t_values):
+        xt = torch.from_numpy(g[f"walk_xt_{j}"].astype(np.int64))
+        out = model(O.one_hot_bchw(xt, K).to(U.DEV), img.to(U.DEV), t=torch.full((N,), float(t)), validation=True)["diffusion_out"]
+        worst = max(worst, np.abs(out.cpu()[:, :, ::4, ::4].numpy() - g[f"walk_x0pred_lattice_{j}"]).max())
+        if t > 1:
+            e = torch.empty(N * H * W, K).exponential_(1)
+            a, c = O.posterior_coeffs(sched[1], sched[2], t)
+            r = U.posterior_sample(U.nhwc(out.cpu()).reshape(N, H * W, K), xt.to(torch.uint8).reshape(N, -1).to(U.DEV), a, c, hip.STEP_SAMPLE,
+                                   softmax=False, noise=e.reshape(N, -1).contiguous().to(U.DEV))
+            flips = max(flips, (r["xt_next"].reshape(N, H, W).numpy() != g[f"walk_xt_{j + 1}"]).mean())
+    parity_log("g18_k40", teacher_forced_max_dx0=worst, teacher_forced_draw_mismatch=flips, bar=1e-4)
+    assert worst < 1e-4 and flips <= 1.0 / (N * H * W) + FREE_RUN_FRAC
+    from ccdm_stochastic_segmentation_amd import OneHotCategoricalBCHW
+    for vote in ("confidence", "majority"):
+        model.step_T_sample, model.rng = vote, "torch_cpu"
+        torch.manual_seed(42)
+        x = OneHotCategoricalBCHW(logits=torch.zeros(N, K, H, W)).sample()
+        out = model(x.to(U.DEV), img.to(U.DEV), t=torch.as_tensor(10006))["diffusion_out"].cpu()
+        if vote == "confidence":
+            mism = (out.argmax(1).numpy() != g["walk_out_argmax"]).mean()
+            err = np.abs(out[:, :, ::2, ::2].numpy() - g["walk_out_lattice"])
+            parity_log("g18_k40", free_running_argmax_mismatch=mism, free_running_max_dp_lattice=err.max())
+            assert mism <= 2.0 / (N * H * W) and (err > 1e-3).mean() <= 1e-3 and np.median(err) < 1e-6
+        else:
+            assert out.dtype == torch.int64
+            mism = (out.argmax(1).numpy() != g["walk_out_majority"]).mean()
+            parity_log("g18_k40", free_running_majority_mismatch=mism)
+            assert mism <= 2.0 / (N * H * W)
+
+
 def test_philox_stream_matches_oracle(U):
     """Throughput-mode RNG: the device Philox4x32-10 stream equals the numpy restatement; indices equal
     argmax(P^/E) with the oracle's E wherever the race is not a last-ulp tie."""

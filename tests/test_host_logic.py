@@ -53,7 +53,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(hip.SIGNATURES), declared ^ set(hip.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ccdm_version() == hip.ABI_VERSION == 9
+    assert lib.ccdm_version() == hip.ABI_VERSION == 10
     assert ctypes.sizeof(hip.ConvArgs) % 8 == 0 and ctypes.sizeof(hip.PostArgs) % 8 == 0
 
 
@@ -202,8 +202,9 @@ def test_auto_substreams_rule():
 
 
 def test_builder_contract():
-    with pytest.raises(ValueError, match="40 classes"):
-        P.build_model(250, "cosine", None, [(3, 64, 64), (40, 64, 64)], (3, 64, 64), "unet_openai", dict(base_channels=32), "datasets.lidc", "confidence", None)
+    with pytest.raises(ValueError, match="256 classes"):         # x_t travels as a uint8 class index
+        P.build_model(250, "cosine", None, [(3, 64, 64), (256, 64, 64)], (3, 64, 64), "unet_openai", dict(base_channels=32), "datasets.lidc", "confidence", None)
+    assert P.build_model(250, "cosine", None, [(3, 64, 64), (40, 64, 64)], (3, 64, 64), "unet_openai", LIDC_BP, "datasets.lidc", "confidence", None).diffusion.num_classes == 40
     with pytest.raises(NotImplementedError, match="backbone resnet50"):
         P.build_model(250, "cosine", None, [(1, 128, 128), (2, 128, 128)], None, "resnet50", {}, "x")
     with pytest.raises(ValueError, match="unsupported image size"):

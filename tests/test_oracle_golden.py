@@ -225,6 +225,63 @@ def test_g15_trajectory_k20(golden):
             assert out.dtype == torch.int64 and np.array_equal(out.argmax(1).numpy(), g["out_majority"])
 
 
+def k40_case():
+    """the G18 walk (tools/gen_goldens_k40.py): a LIDC-shaped network with 40 classes, 32x32, N = 2"""
+    spec = make_unet_spec(image_size=32, in_channels=43, out_channels=40, **dict(LIDC_BP, channel_mult=[1, 2, 4], attention_resolutions=[8]))
+    sd = {k: torch.from_numpy(v) for k, v in make_synthetic_state_dict(spec, 18).items()}
+    rng = np.random.default_rng(18)
+    img = torch.from_numpy(rng.uniform(-1, 1, (2, 3, 32, 32)).astype(np.float32))
+    return spec, sd, img
+
+
+def test_g18_forty_classes(golden):
+    """More than 32 classes, pinned on the reference itself (K = 40): its O(K^2) posterior, its sampler's normalisation and draws given
+    the noise torch drew, and a seeded 6-step strided walk (per-step class maps, lattice outputs, final probabilities, majority map)."""
+    g = golden["g18_k40"]
+    K = 40
+    _, alphas, cum = O.make_schedule("cosine", 250, {"s": 0.008})
+    xt = O.one_hot_bchw(torch.from_numpy(g["post_xt"].astype(np.int64)), K)
+    x0 = torch.from_numpy(g["post_x0"])
+    for t in (250, 125, 2, 1):
+        a, c = O.posterior_coeffs(alphas, cum, t)
+        np.testing.assert_allclose(O.theta_post_prob_ref(xt, x0, a, c).numpy(), g[f"post_t{t}"], rtol=0, atol=1e-7)
+        np.testing.assert_allclose(O.theta_post_prob(xt, x0, a, c).numpy(), g[f"post_t{t}"], rtol=0, atol=2e-6)
+    probs = torch.from_numpy(g["smp_probs"])
+    p_hat = O.normalise_probs(probs)
+    assert np.array_equal(p_hat.numpy(), g["smp_phat"])
+    noise = torch.from_numpy(g["smp_noise"]).reshape(*p_hat.shape)
+    assert np.array_equal(O.sample_index(p_hat, noise).numpy(), g["smp_idx"])
+    assert np.array_equal(p_hat.argmax(-1).numpy(), g["smp_maxprob"])
+    # the cascade order the HIP epilogue implements (two 16-blocks, then the 8-class tail): equal to torch's sum wherever torch took it
+    pcl = probs.permute(0, 2, 3, 1).contiguous()
+    s_torch = probs.permute(0, 2, 3, 1).sum(-1)                # (the channels-last VIEW the reference's Categorical sums over)
+    s_casc, s_rows = O.ordered_sum_lastdim(pcl), O.row_sum_order_lastdim(pcl)
+    assert ((s_casc == s_torch) | (s_rows == s_torch)).all() and (s_casc == s_torch).float().mean() > 0.5
+    np.testing.assert_allclose(O.normalise_probs(probs, order="cascade").numpy(), p_hat.numpy(), rtol=3e-7)
+    # the walk
+    _, sd, img = k40_case()
+    sched = O.make_schedule("cosine", 250, {"s": 0.008})
+    for vote in ("confidence", "majority"):
+        torch.manual_seed(42)
+        idx, _ = O.draw_x_T(2, K, 32, 32)
+        assert np.array_equal(idx.numpy(), g["walk_xT"])
+        trace = []
+        out = O.forward_denoising(sd, LIDC_CFG, sched, O.one_hot_bchw(idx, K), img, None, 10006, vote, trace=trace)["diffusion_out"]
+        assert [r["t"] for r in trace] == list(g["walk_t_values"])
+        cur = idx
+        for j, r in enumerate(trace):
+            assert np.array_equal(cur.numpy(), g[f"walk_xt_{j}"]), f"x_t differs at step {j}"
+            np.testing.assert_allclose(r["x0pred"][:, :, ::4, ::4].numpy(), g[f"walk_x0pred_lattice_{j}"], atol=2e-6)
+            if "idx" in r:
+                cur = r["idx"]
+        if vote == "confidence":
+            assert np.array_equal(out.argmax(1).numpy(), g["walk_out_argmax"])
+            np.testing.assert_allclose(out[:, :, ::2, ::2].numpy(), g["walk_out_lattice"], atol=2e-6)
+            np.testing.assert_allclose(out.double().sum((2, 3)).numpy(), g["walk_out_class_sums"], rtol=1e-6)
+        else:
+            assert out.dtype == torch.int64 and np.array_equal(out.argmax(1).numpy(), g["walk_out_majority"])
+
+
 def heads_meta():
     import json
     import os
