@@ -1192,6 +1192,12 @@ int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
                                               (up2 ? packed_frag_bytes(4 * a.Cout, C, 2, prec) : packed_frag_bytes(a.Cout, C, a.ksize, prec)));
     const int want_slices = (up2 && NI == 1 ? 4 : 1) * k.slices;      // one phase per block: every (slice, phase) pair leaves a partial
     if (a.out_stats) CCDM_REQUIRE(a.out_slices == want_slices, "conv: out_slices %d != %d", a.out_slices, want_slices);
+    if (up2 && upconv_eligible(a)) {               // low-resolution Upsample convs: wave = phase, weight fragments straight from L2
+        const int rcu = launch_upconv(a, k.slices, k.ntiles, k.wscale, s);
+        if (rcu) return rcu;
+        CCDM_CHECK_LAUNCH("upconv");
+        return 0;
+    }
     if (conv1x1_eligible(a, k.slices)) {           // AttentionBlock.proj_out + residual at the low-resolution stages: no LDS staging at all
         const int rc1 = launch_conv1x1(a, k.slices, k.ntiles, k.wscale, s);
         if (rc1) return rc1;

@@ -71,6 +71,9 @@ int launch_conv1x1(const ccdm_conv_args& a, int slices, int ntiles, const float*
 bool conv_ks_eligible(const ccdm_conv_args& a);
 int conv_ks_slices(const ccdm_conv_args& a);            // statistics slices that kernel leaves (one per 8x8 tile)
 int launch_conv_ks(const ccdm_conv_args& a, int ntiles, const float* wscale, hipStream_t s);
+// Upsample + conv 3x3 in sub-pixel form at the low-resolution decoder levels: wave = phase, weight fragments straight from L2 (ccdm_upconv.hip)
+bool upconv_eligible(const ccdm_conv_args& a);
+int launch_upconv(const ccdm_conv_args& a, int slices, int ntiles, const float* wscale, hipStream_t s);
 #ifdef CCDM_ABLATION
 bool conv_ks_timeline_read(unsigned long long* host, int n);
 #endif

@@ -155,6 +155,35 @@ def test_upsample_conv_subpixel_form(U, cin, cout, H, W):
     np.testing.assert_allclose(st[..., 1].numpy(), (gd * gd).sum((2, 3)).numpy(), rtol=2e-6, atol=0)
 
 
+@pytest.mark.parametrize("cin,cout,H,W,N", [(64, 64, 32, 32, 64), (64, 64, 32, 32, 3), (96, 96, 16, 16, 5), (128, 128, 16, 32, 2), (64, 128, 8, 16, 3),
+                                              (128, 64, 24, 16, 2)])
+def test_upsample_conv_wave_per_phase_kernel(U, cin, cout, H, W, N):
+    """ccdm_upconv.hip (low-resolution Upsample convs: wave = phase, weight fragments straight from L2, the halo tile staged once with every
+    input channel): the same products in the same order as the general kernel's sub-pixel form — outputs identical bit for bit
+    (CCDM_DIAG_GENERAL_KERNEL routes the same call to that kernel), statistics partials of the same shape that add up to the same sums;
+    both block shapes (two channel tiles per block from one staged tile at N = 64, one otherwise); run-to-run and shard bit-identity."""
+    rng = np.random.default_rng(cin + cout + H + W + N)
+    x = rnd(rng, N, cin, H, W) * 1.5 + 0.3
+    w = rnd(rng, cout, cin, 3, 3) / np.sqrt(cin * 9)
+    b = rnd(rng, cout, scale=0.1)
+    xs = U.nhwc(x)
+    out, ost = U.conv2d([xs], w.numpy(), b.numpy(), 3, up=2, prec=hip.PREC_F16X3)
+    gen, gst = U.conv2d([xs], w.numpy(), b.numpy(), 3, up=2, prec=hip.PREC_F16X3, diag=hip.DIAG_GENERAL_KERNEL)
+    assert torch.equal(out, gen)
+    assert ost.shape == gst.shape
+    np.testing.assert_allclose(ost.cpu().sum(1).numpy(), gst.cpu().sum(1).numpy(), rtol=1e-6, atol=1e-4)
+    ref = F.conv2d(F.interpolate(x[:2].double(), scale_factor=2, mode="nearest"), w.double(), b.double(), padding=1)
+    np.testing.assert_allclose(U.bchw(out[:2]).numpy(), ref.float().numpy(), rtol=0, atol=2e-5)
+    gd = U.bchw(out).double()
+    st = ost.cpu().sum(1)
+    np.testing.assert_allclose(st[..., 0].numpy(), gd.sum((2, 3)).numpy(), rtol=0, atol=2e-6 * gd.abs().sum((2, 3)).max().item())
+    np.testing.assert_allclose(st[..., 1].numpy(), (gd * gd).sum((2, 3)).numpy(), rtol=2e-6, atol=0)
+    out2, ost2 = U.conv2d([xs], w.numpy(), b.numpy(), 3, up=2, prec=hip.PREC_F16X3)
+    assert torch.equal(out, out2) and torch.equal(ost, ost2)
+    sh, sst = U.conv2d([xs[1:2].contiguous()], w.numpy(), b.numpy(), 3, up=2, prec=hip.PREC_F16X3)
+    assert torch.equal(sh, out[1:2]) and torch.equal(sst, ost[1:2])
+
+
 @pytest.mark.parametrize("c0,cout,H,W,k,stride,up", [(32, 32, 128, 128, 3, 1, 0), (64, 32, 64, 64, 3, 1, 0), (32, 32, 128, 128, 3, 2, 0),
                                                      (32, 32, 64, 64, 3, 1, 2), (32, 32, 72, 40, 3, 1, 0), (96, 96, 16, 16, 1, 1, 0),
                                                      (96, 96, 16, 16, 3, 1, 0)])
