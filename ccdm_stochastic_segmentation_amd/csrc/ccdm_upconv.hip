@@ -14,7 +14,7 @@
 //     input tile, so a weight fragment is needed by exactly one wave, which reads it straight from L2 into the registers the MFMA takes
 //     it from (two requests ahead): no LDS staging of B, no barrier for it, 12 matrix instructions per 2 KB fragment pair.
 //   * the halo tile (10 x 18 pixels) is staged ONCE per tile with ALL input channels (raw input: x 2^4, fp16 hi/lo split, pitch 4 C + 16
-//     bytes: conflict-free 16-byte fragment reads for C in {64, 96, 128}): one barrier in front of the matrix phase;
+//     bytes: conflict-free 16-byte fragment reads for C in {32, 64, 96, 128}): one barrier in front of the matrix phase;
 //   * a block may walk several 32-channel output tiles from one staged tile (ctb: a partitioning choice only).
 // Same products in the same order as the general kernel's form (k-step outer, window tap inner; lo*hi, hi*lo, hi*hi): identical outputs
 // (tested bit for bit through CCDM_DIAG_GENERAL_KERNEL); the output statistics are one partial per (sample, slice) like its, the four
@@ -88,6 +88,7 @@ __global__ __launch_bounds__(256, 2) void k_upconv(const UpK k) {
         for (int e = 0; e < 4; ++e) { s1[c][e] = 0.f; s2[c][e] = 0.f; }
 
     const int ntile_sp = k.tiles_x * k.tiles_y;
+#pragma unroll 1
     for (int t = slice; t < ntile_sp; t += k.slices) {
         const int ty = t / k.tiles_x, tx = t - ty * k.tiles_x;
         const int oy0 = ty * UP_TH, ox0 = tx * UP_TW;
@@ -130,6 +131,7 @@ __global__ __launch_bounds__(256, 2) void k_upconv(const UpK k) {
         }
         __syncthreads();
 
+#pragma unroll 1
         for (int ct = 0; ct < k.ctb; ++ct) {
             const int nt = 4 * (ct0 + ct) + wave;                                      // this wave's n-tile of the packed 2x2 conv
             // fragment (k-step ks, window tap bt): slab ((bt * KS16 + ks) * ntiles + nt) of 2 KB, hi then lo
@@ -241,9 +243,12 @@ __global__ __launch_bounds__(256, 2) void k_upconv(const UpK k) {
 bool upconv_eligible(const ccdm_conv_args& a) {
     if (a.prec != CCDM_PREC_F16X3 || a.up != 2) return false;                           // (a diagnostic bit in prec >> 8: the general kernel)
     if (a.C1 || a.in1 || a.stats0 || a.act != CCDM_ACT_NONE || a.film || a.emb_off >= 0 || a.resid || a.skip0 || a.fine_slices) return false;
-    if (!(a.C0 == 64 || a.C0 == 96 || a.C0 == 128) || a.Cout % 32) return false;       // (32 channels occur at 64x64 inputs and up only)
-    // low-resolution levels only (a rule of the geometry, never of the batch): whole 8x16 tiles, at most 1024 input pixels
-    return a.Hin % UP_TH == 0 && a.Win % UP_TW == 0 && a.Hin * a.Win <= 1024;
+    if (!(a.C0 == 32 || a.C0 == 64 || a.C0 == 96 || a.C0 == 128) || a.Cout % 32) return false;
+    // a rule of the geometry, never of the batch: whole 8x16 tiles
+#ifdef CCDM_UP_MAXPX
+    if (a.Hin * a.Win > CCDM_UP_MAXPX) return false;
+#endif
+    return a.Hin % UP_TH == 0 && a.Win % UP_TW == 0;
 }
 
 template <int C>
@@ -272,6 +277,7 @@ int launch_upconv(const ccdm_conv_args& a, int slices, int ntiles, const float* 
     const dim3 grid(a.N * slices, ctiles / k.ctb);
     const bool alias = k.ctb == 1;
     switch (a.C0) {
+        case 32: return launch_upconv_c<32>(k, grid, alias, s);
         case 64: return launch_upconv_c<64>(k, grid, alias, s);
         case 96: return launch_upconv_c<96>(k, grid, alias, s);
         default: return launch_upconv_c<128>(k, grid, alias, s);
