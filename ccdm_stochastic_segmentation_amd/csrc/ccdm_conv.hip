@@ -229,7 +229,9 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
     // weight fragments by LDS-DMA instead of through registers — on the narrow-tile variants, where the B chunk (36-74 KB) outweighs the
     // halo tile: same-box A/B per stage 16x16 423 -> 402 us, 32x32 420 -> 414 us per denoise step; the wide-tile variants LOSE with it
     // (128x128 1358 -> 1378 us: the request sits behind barrier A instead of in front of it, and their chunk is only 18 KB)
-    constexpr bool BDMA = CCDM_BDMA && PREC != CCDM_PREC_F32 && TW < 32;
+    // (not the stride-2 variants: their commit is short — raw input — so the DMA's round trip sat exposed between the two barriers:
+    //  Downsample 128x128 -> 64x64 61.2 -> 58.9 us, 64x64 -> 32x32 20.6 -> 19.8 us through registers, round 5)
+    constexpr bool BDMA = CCDM_BDMA && PREC != CCDM_PREC_F32 && TW < 32 && STRIDE == 1;
     f32x4 regB[1][(NITEM_B > 0 && !BDMA) ? NITEM_B : 1];
     unsigned valid[DEPTH];         // generic walk: bit i = item i lies inside the image
     unsigned rowmask[DEPTH];       // row-structured: bit i = core row of pass i inside the image (wave-uniform)

@@ -36,7 +36,7 @@ struct UpK {
     int N, Hin, Win, Cout, ntiles, slices, tiles_x, tiles_y, ctb;
 };
 
-constexpr int UP_TH = 8, UP_TW = 16, UP_HH = UP_TH + 2, UP_HW = UP_TW + 2, UP_HP = UP_HH * UP_HW;
+constexpr int UP_TH = 8, UP_HH = UP_TH + 2;
 constexpr int UP_EPS = 36;                                     // floats per pixel row of the transpose buffer
 constexpr int UP_EPI_BYTES = 4 * 32 * UP_EPS * 4;              // four wave-private [32 pixels][36] buffers
 constexpr int UP_CTB_MAX = 2;
@@ -45,17 +45,21 @@ constexpr int UP_CTB_MAX = 2;
 #endif
 constexpr int UP_BD = CCDM_UP_BDEPTH;                         // weight fragments requested ahead of the one being multiplied
 
-template <int C> struct UpGeo {
+// TW = 16: 8x16 input tiles, four 32-pixel sub-tiles per wave; TW = 8 (8-pixel-wide inputs: LIDC's 8x8 -> 16x16 launch): 8x8 tiles, two
+// sub-tiles per wave, and — like the general kernel's one-phase-per-block form there — one statistics partial per (slice, PHASE)
+template <int C, int TW> struct UpGeo {
     static constexpr int PIXB = 4 * C + 16, QPP = C / 4, KS16 = C / 16, NF = KS16 * 4;
-    static constexpr int A_BYTES = UP_HP * PIXB;
-    static constexpr int NITEMS = (UP_HP * QPP + 255) / 256;
+    static constexpr int HW = TW + 2, HP = UP_HH * HW, MT = UP_TH * TW / 32;
+    static constexpr int A_BYTES = HP * PIXB;
+    static constexpr int NITEMS = (HP * QPP + 255) / 256;
 };
 
 // ALIAS: the epilogue's transpose rows (and the statistics fold) alias the halo tile — one channel tile per block, one more barrier
-template <int C, bool ALIAS>
+template <int C, int TW, bool ALIAS>
 __global__ __launch_bounds__(256, 2) void k_upconv(const UpK k) {
-    using G = UpGeo<C>;
+    using G = UpGeo<C, TW>;
     constexpr int PIXB = G::PIXB, QPP = G::QPP, KS16 = G::KS16, NF = G::NF, NITEMS = G::NITEMS;
+    constexpr int UP_TW = TW, UP_HW = G::HW, UP_HP = G::HP, MT = G::MT;
     extern __shared__ __attribute__((aligned(16))) char smem_up[];
     char* const tile = smem_up;
     float* const epi_all = reinterpret_cast<float*>(ALIAS ? smem_up : smem_up + G::A_BYTES);
@@ -72,9 +76,9 @@ __global__ __launch_bounds__(256, 2) void k_upconv(const UpK k) {
     char* const out_n = reinterpret_cast<char*>(k.out + (size_t)n * 4 * k.Hin * k.Win * Cout);
 
     // this lane's A-fragment base of each 32-pixel sub-tile: pixel p = 32 mi + (lane & 31) of the 8x16 tile, window origin (dy, dx)
-    int hpb[4];
+    int hpb[MT];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
+    for (int mi = 0; mi < MT; ++mi) {
         const int p = mi * 32 + (lane & 31);
         hpb[mi] = ((p / UP_TW + dy) * UP_HW + (p % UP_TW + dx)) * PIXB + (lane >> 5) * 16;
     }
@@ -137,7 +141,11 @@ __global__ __launch_bounds__(256, 2) void k_upconv(const UpK k) {
             // fragment (k-step ks, window tap bt): slab ((bt * KS16 + ks) * ntiles + nt) of 2 KB, hi then lo
             const char* const wb = static_cast<const char*>(k.w) + ((size_t)nt << 11);
             const unsigned wstep = (unsigned)k.ntiles << 11;                            // bytes between consecutive (bt, ks) slabs
-            auto frag_off = [&](const int j) { return (unsigned)((j & 3) * KS16 + (j >> 2)) * wstep; };       // j = 4 ks + bt
+            // walk order j -> (k-step, window tap): k-step outer, tap inner for the 8x16 tiles; for the 8x8 tiles pairs of k-steps outer, tap, then
+            // the pair's two k-steps — each the order in which the general kernel's form of the same geometry accumulates (16- / 32-channel chunks)
+            auto ks_of = [&](const int j) { return TW == 8 ? 2 * (j >> 3) + (j & 1) : j >> 2; };
+            auto bt_of = [&](const int j) { return TW == 8 ? (j & 7) >> 1 : j & 3; };
+            auto frag_off = [&](const int j) { return (unsigned)(bt_of(j) * KS16 + ks_of(j)) * wstep; };
             f32x4 bq[UP_BD + 1][2];
             auto issue_b = [&](const int j) {
                 bq[j % (UP_BD + 1)][0] = load16_uniform_base(wb + frag_off(j), (unsigned)lane << 4);
@@ -147,18 +155,18 @@ __global__ __launch_bounds__(256, 2) void k_upconv(const UpK k) {
             for (int j = 0; j < UP_BD; ++j) issue_b(j);
             const float add = k.bias ? k.bias[min((ct0 + ct) * 32 + (lane & 31), Cout - 1)] : 0.f;
             const float wsc = k.wscale[nt * 32 + (lane & 31)];
-            f32x16 acc[4];
+            f32x16 acc[MT];
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
             // software pipeline, one step deep: the A fragments of step j + 1 (8 LDS reads) and the B fragment of step j + 2 are requested in
             // front of the 12 MFMAs of step j (sched_barrier pins the order — the scheduler otherwise hoists reads until the registers are gone)
-            f16x8 ah[2][4], al[2][4];
+            f16x8 ah[2][MT], al[2][MT];
             auto load_a = [&](const int buf, const int j) {
-                const int toff = (((j & 3) >> 1) * UP_HW + (j & 1)) * PIXB + 32 * (j >> 2);
+                const int toff = ((bt_of(j) >> 1) * UP_HW + (bt_of(j) & 1)) * PIXB + 32 * ks_of(j);
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi) {
+                for (int mi = 0; mi < MT; ++mi) {
                     ah[buf][mi] = *reinterpret_cast<const f16x8*>(tile + hpb[mi] + toff);
                     al[buf][mi] = *reinterpret_cast<const f16x8*>(tile + hpb[mi] + toff + 2 * C);
                 }
@@ -171,11 +179,11 @@ __global__ __launch_bounds__(256, 2) void k_upconv(const UpK k) {
                 __builtin_amdgcn_sched_barrier(0);
                 const f16x8 bh = __builtin_bit_cast(f16x8, bq[j % (UP_BD + 1)][0]), bl = __builtin_bit_cast(f16x8, bq[j % (UP_BD + 1)][1]);
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[j & 1][mi], bh, acc[mi], 0, 0, 0);
+                for (int mi = 0; mi < MT; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[j & 1][mi], bh, acc[mi], 0, 0, 0);
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j & 1][mi], bl, acc[mi], 0, 0, 0);
+                for (int mi = 0; mi < MT; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j & 1][mi], bl, acc[mi], 0, 0, 0);
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j & 1][mi], bh, acc[mi], 0, 0, 0);
+                for (int mi = 0; mi < MT; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j & 1][mi], bh, acc[mi], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
             // ---- epilogue: (x 2^-e) + bias -> wave-private transpose -> float4 rows to pixel (2y + dy, 2x + dx), statistics ----
@@ -184,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void k_upconv(const UpK k) {
             // lane (prow, cq): tile column col0 + prow = 2 prow output pixels to the right of the row pass's first one, channel quad cq
             const unsigned lane_off = ((unsigned)(2 * prow) * (unsigned)Cout + (unsigned)((ct0 + ct) * 32 + 4 * cq)) << 2;
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
+            for (int mi = 0; mi < MT; ++mi) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int pl = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -192,10 +200,10 @@ __global__ __launch_bounds__(256, 2) void k_upconv(const UpK k) {
                 }
 #pragma unroll
                 for (int jr = 0; jr < 4; ++jr) {
-                    // row pass jr: tile pixel p = 32 mi + 8 jr + prow -> tile row 2 mi + (jr >> 1), column 8 (jr & 1) + prow
+                    // row pass jr: tile pixel p = 32 mi + 8 jr + prow -> tile row (32 mi + 8 jr) / TW, column (8 jr) % TW + prow
                     const int pl = jr * 8 + prow;
                     const f32x4 o = *reinterpret_cast<const f32x4*>(epi + pl * UP_EPS + 4 * cq);
-                    const int row = 2 * mi + (jr >> 1), col0 = 8 * (jr & 1);
+                    const int row = (32 * mi + 8 * jr) / UP_TW, col0 = (8 * jr) % UP_TW;
                     const unsigned rb = (unsigned)(((2 * (oy0 + row) + dy) * Wout + 2 * (ox0 + col0) + dx) * Cout) << 2;      // uniform
                     store16_uniform_base(out_n + rb, lane_off, o);
 #pragma unroll
@@ -227,15 +235,25 @@ __global__ __launch_bounds__(256, 2) void k_upconv(const UpK k) {
                 }
             }
         __syncthreads();
-        for (int i = tid; i < k.ctb * 32; i += 256) {
-            const int c = i >> 5, l = i & 31;
-            double a1 = 0.0, a2 = 0.0;
-            for (int w = 0; w < 4; ++w) {
-                a1 += red[((w * UP_CTB_MAX + c) * 32 + l) * 2 + 0];
-                a2 += red[((w * UP_CTB_MAX + c) * 32 + l) * 2 + 1];
+        if constexpr (TW == 8) {
+            // one partial per (slice, phase): slot = 4 * slice + phase, as the general kernel's one-phase-per-block form leaves them
+            for (int i = tid; i < 4 * k.ctb * 32; i += 256) {
+                const int w = i / (k.ctb * 32), c = (i / 32) % k.ctb, l = i & 31;
+                double* o = k.out_stats + (((size_t)n * 4 * k.slices + 4 * slice + w) * Cout + (ct0 + c) * 32 + l) * 2;
+                o[0] = red[((w * UP_CTB_MAX + c) * 32 + l) * 2 + 0];
+                o[1] = red[((w * UP_CTB_MAX + c) * 32 + l) * 2 + 1];
             }
-            double* o = k.out_stats + (((size_t)n * k.slices + slice) * Cout + (ct0 + c) * 32 + l) * 2;
-            o[0] = a1; o[1] = a2;
+        } else {
+            for (int i = tid; i < k.ctb * 32; i += 256) {
+                const int c = i >> 5, l = i & 31;
+                double a1 = 0.0, a2 = 0.0;
+                for (int w = 0; w < 4; ++w) {
+                    a1 += red[((w * UP_CTB_MAX + c) * 32 + l) * 2 + 0];
+                    a2 += red[((w * UP_CTB_MAX + c) * 32 + l) * 2 + 1];
+                }
+                double* o = k.out_stats + (((size_t)n * k.slices + slice) * Cout + (ct0 + c) * 32 + l) * 2;
+                o[0] = a1; o[1] = a2;
+            }
         }
     }
 }
@@ -244,28 +262,32 @@ bool upconv_eligible(const ccdm_conv_args& a) {
     if (a.prec != CCDM_PREC_F16X3 || a.up != 2) return false;                           // (a diagnostic bit in prec >> 8: the general kernel)
     if (a.C1 || a.in1 || a.stats0 || a.act != CCDM_ACT_NONE || a.film || a.emb_off >= 0 || a.resid || a.skip0 || a.fine_slices) return false;
     if (!(a.C0 == 32 || a.C0 == 64 || a.C0 == 96 || a.C0 == 128) || a.Cout % 32) return false;
-    // a rule of the geometry, never of the batch: whole 8x16 tiles
+    // a rule of the geometry, never of the batch: whole 8x16 tiles, or 8x8 tiles for 8-pixel-wide inputs (where the general rule tiles 8x8 too)
 #ifdef CCDM_UP_MAXPX
     if (a.Hin * a.Win > CCDM_UP_MAXPX) return false;
 #endif
-    return a.Hin % UP_TH == 0 && a.Win % UP_TW == 0;
+    return a.Hin % UP_TH == 0 && (a.Win % 16 == 0 || a.Win == 8);
 }
 
-template <int C>
-static int launch_upconv_c(const UpK& k, dim3 grid, bool alias, hipStream_t s) {
-    const size_t lds = alias ? (size_t)std::max(UpGeo<C>::A_BYTES, UP_EPI_BYTES) : (size_t)UpGeo<C>::A_BYTES + UP_EPI_BYTES;
-    auto kern = alias ? k_upconv<C, true> : k_upconv<C, false>;
+template <int C, int TW>
+static int launch_upconv_ct(const UpK& k, dim3 grid, bool alias, hipStream_t s) {
+    const size_t lds = alias ? (size_t)std::max(UpGeo<C, TW>::A_BYTES, UP_EPI_BYTES) : (size_t)UpGeo<C, TW>::A_BYTES + UP_EPI_BYTES;
+    auto kern = alias ? k_upconv<C, TW, true> : k_upconv<C, TW, false>;
     if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return fail("upconv: cannot reserve %zu bytes of LDS", lds);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, k);
     return 0;
+}
+template <int C>
+static int launch_upconv_c(const UpK& k, dim3 grid, bool alias, hipStream_t s) {
+    return k.Win == 8 ? launch_upconv_ct<C, 8>(k, grid, alias, s) : launch_upconv_ct<C, 16>(k, grid, alias, s);
 }
 
 int launch_upconv(const ccdm_conv_args& a, int slices, int ntiles, const float* wscale, hipStream_t s) {
     UpK k;
     k.in = a.in0; k.w = a.w; k.wscale = wscale; k.bias = a.bias; k.out = a.out; k.out_stats = a.out_stats;
     k.N = a.N; k.Hin = a.Hin; k.Win = a.Win; k.Cout = a.Cout; k.ntiles = ntiles; k.slices = slices;
-    k.tiles_x = a.Win / UP_TW; k.tiles_y = a.Hin / UP_TH;
+    k.tiles_x = a.Win == 8 ? 1 : a.Win / 16; k.tiles_y = a.Hin / UP_TH;
     // channel tiles per block: two from one staged tile while >= 512 blocks remain (a partitioning choice only: every output element
     // and every statistics partial is computed by the same instruction sequence either way)
     const int ctiles = a.Cout / 32;

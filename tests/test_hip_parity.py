@@ -156,7 +156,7 @@ def test_upsample_conv_subpixel_form(U, cin, cout, H, W):
 
 
 @pytest.mark.parametrize("cin,cout,H,W,N", [(64, 64, 32, 32, 64), (64, 64, 32, 32, 3), (96, 96, 16, 16, 5), (128, 128, 16, 32, 2), (64, 128, 8, 16, 3),
-                                              (128, 64, 24, 16, 2), (64, 64, 72, 96, 2), (96, 64, 128, 256, 2), (32, 32, 64, 64, 3), (32, 64, 16, 48, 2)])
+                                              (128, 64, 24, 16, 2), (64, 64, 72, 96, 2), (96, 64, 128, 256, 2), (32, 32, 64, 64, 3), (32, 64, 16, 48, 2), (128, 128, 8, 8, 5), (64, 96, 24, 8, 2)])
 def test_upsample_conv_wave_per_phase_kernel(U, cin, cout, H, W, N):
     """ccdm_upconv.hip (low-resolution Upsample convs: wave = phase, weight fragments straight from L2, the halo tile staged once with every
     input channel): the same products in the same order as the general kernel's sub-pixel form — outputs identical bit for bit
