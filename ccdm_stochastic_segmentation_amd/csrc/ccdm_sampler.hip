@@ -247,8 +247,12 @@ int launch_posterior(const ccdm_post_args& a, hipStream_t s) {
     if (!npix) return 0;
     if (a.K > 32 || (a.softmax & CCDM_POST_DIAG_MANY)) {       // LDS-resident classes, run-time loops (any K; the diagnostic bit: parity tests at K <= 32)
         const size_t lds = (size_t)128 * (a.K | 1) * sizeof(float);
-        if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k_posterior_many), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return fail("posterior: cannot reserve %zu bytes of LDS for K=%d", lds, a.K);
+        static size_t reserved = 64 * 1024;               // (raised once per size class, not on every enqueue)
+        if (lds > reserved) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_posterior_many), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return fail("posterior: cannot reserve %zu bytes of LDS for K=%d", lds, a.K);
+            reserved = 160 * 1024;
+        }
         hipLaunchKernelGGL(k_posterior_many, dim3((unsigned)((npix + 127) / 128)), dim3(128), lds, s, a);
         CCDM_CHECK_LAUNCH("posterior(many classes)");
         return 0;

@@ -273,8 +273,12 @@ template <int C, int TW>
 static int launch_upconv_ct(const UpK& k, dim3 grid, bool alias, hipStream_t s) {
     const size_t lds = alias ? (size_t)std::max(UpGeo<C, TW>::A_BYTES, UP_EPI_BYTES) : (size_t)UpGeo<C, TW>::A_BYTES + UP_EPI_BYTES;
     auto kern = alias ? k_upconv<C, TW, true> : k_upconv<C, TW, false>;
-    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return fail("upconv: cannot reserve %zu bytes of LDS", lds);
+    static bool configured[2] = {false, false};          // (per instantiation and form: the attribute is set once, not on every enqueue)
+    if (lds > 64 * 1024 && !configured[alias ? 1 : 0]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return fail("upconv: cannot reserve %zu bytes of LDS", lds);
+        configured[alias ? 1 : 0] = true;
+    }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, k);
     return 0;
 }
