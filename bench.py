@@ -263,8 +263,9 @@ def main():
     ap.add_argument("--rng", choices=["philox", "torch_cpu"], default="philox",
                     help="philox: noise generated in the epilogue kernel (the benchmark); torch_cpu: the parity mode — Exp(1) noise drawn "
                          "on the host in the reference's order and copied over PCIe (host-RNG bound; reported for DESIGN.md, never the headline)")
-    ap.add_argument("--prec", choices=["f32", "f16x3"], default="f16x3",
-                    help="conv arithmetic: exact fp32 MFMA, or fp16 hi/lo split x3 MFMA with fp32 accumulate (~2^-22)")
+    ap.add_argument("--prec", choices=["f32", "f16x3", "f16"], default="f16x3",
+                    help="conv arithmetic: exact fp32 MFMA, or fp16 hi/lo split x3 MFMA with fp32 accumulate (~2^-22: the benchmarked default); "
+                         "f16 = the OPT-IN single-pass fast mode (operands rounded to fp16, outside the parity contract: a diagnostic line, never the metric)")
     ap.add_argument("--slicing", default="throughput", choices=["throughput", "latency"],
                     help="DenoisingModel.slicing: 'latency' = more, shorter conv workgroups per sample (small batches)")
     ap.add_argument("--per-op", default="", help="write the per-op table of the tapped pass to this file (JSON)")
@@ -307,7 +308,8 @@ def main():
     model.unet.load_state_dict(sd, strict=True)
     model = model.to(dev).eval()
     f16 = args.prec == "f16x3"
-    model.prec = hip.PREC_F16X3 if f16 else hip.PREC_F32
+    single = args.prec == "f16"
+    model.prec = hip.PREC_F16X3 if f16 else (hip.PREC_F16 if single else hip.PREC_F32)
     model.rng, model.philox_seed = args.rng, 2024
     # the timed configuration is the product default (DenoisingModel: HIP-graph replay, automatic sub-batching) unless overridden
     if args.graph >= 0:
@@ -395,7 +397,9 @@ def main():
             "metric": f"segmentation samples/sec, {'LIDC 128x128' if K == 2 else f'Cityscapes {H}x{W}'} T={T}", "value": total / dt, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_pass,
             "ms_per_denoise_step": ms_dstep, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if not f16 else "f32 (conv products as split fp16 hi/lo x3 on MFMA, fp32 accumulate)", "data": "synthetic",
+            "dtype": ("f32 (conv products as split fp16 hi/lo x3 on MFMA, fp32 accumulate)" if f16 else
+                      "f16 operands (ONE fp16 MFMA per product, fp32 accumulate): opt-in fast mode, NARROWER than the reference's arithmetic - not the metric" if single
+                      else "f32"), "data": "synthetic",
             "config": {"workload": f"{cfg['title']}, batch={n} per GPU, "
                                    f"{'device Philox RNG' if args.rng == 'philox' else 'host torch-CPU Exp(1) noise over PCIe (parity mode)'}, random-init weights",
                        "name": args.config, "global_batch": n * world, "time_steps": T, "denoise_steps_run": n_dsteps,
@@ -413,7 +417,7 @@ def main():
         fr = step_bytes / (ms_dstep * 1e-3) / 1e9
         res["roofline_step"] = {"bound": "hbm", "achieved": fr, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fr / HBM_PEAK_GBS,
                                 "note": f"whole denoise step per GPU in the TIMED region: SURVEY 8(d) {cfg['algo_mb']} MB/sample + {cfg['weights_mb']} MB weights, over ms_per_denoise_step",
-                                "algorithmic_tflops": cfg["gflop"] * n / ms_dstep, "mfma_util": (3.0 if f16 else 16.0) * cfg["gflop"] * n / ms_dstep / MFMA_PEAK_TFLOPS}
+                                "algorithmic_tflops": cfg["gflop"] * n / ms_dstep, "mfma_util": (3.0 if f16 else (1.0 if single else 16.0)) * cfg["gflop"] * n / ms_dstep / MFMA_PEAK_TFLOPS}
         res["roofline"] = None
 
     # ---- untimed, rank 0 at N = 1: ONE single-stream eager pass with HIP-event taps on every op (on the engine's stream) -> the dominant

@@ -482,12 +482,19 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
                 u32x2 hi, lo;
                 unsigned h0, l0, h1, l1;
-                split2_f16(v.x, v.y, h0, l0);
-                split2_f16(v.z, v.w, h1, l1);
-                hi[0] = h0; hi[1] = h1; lo[0] = l0; lo[1] = l1;
                 char* d = halo_b + hp * PIXB + 8 * tq;
-                *reinterpret_cast<u32x2*>(d) = hi;
-                *reinterpret_cast<u32x2*>(d + 2 * CK) = lo;
+                if constexpr (PREC == CCDM_PREC_F16) {          // single-pass mode: the hi halves only (the lo plane of the tile is never read)
+                    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h0) : "v"(v.x), "v"(v.y));
+                    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h1) : "v"(v.z), "v"(v.w));
+                    hi[0] = h0; hi[1] = h1;
+                    *reinterpret_cast<u32x2*>(d) = hi;
+                } else {
+                    split2_f16(v.x, v.y, h0, l0);
+                    split2_f16(v.z, v.w, h1, l1);
+                    hi[0] = h0; hi[1] = h1; lo[0] = l0; lo[1] = l1;
+                    *reinterpret_cast<u32x2*>(d) = hi;
+                    *reinterpret_cast<u32x2*>(d + 2 * CK) = lo;
+                }
             }
         };
         auto put_zero = [&](const int hp) {          // a halo row outside the image (wave-uniform): zeros, no arithmetic
@@ -698,10 +705,12 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
             auto frag_mfma = [&](const int buf) {
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
+                    if constexpr (PREC != CCDM_PREC_F16) {          // (the opt-in single-pass mode multiplies the hi halves only)
 #pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[buf][mi], bh[buf][ni], acc[mi][ni], 0, 0, 0);
+                        for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[buf][mi], bh[buf][ni], acc[mi][ni], 0, 0, 0);
 #pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[buf][mi], bl[buf][ni], acc[mi][ni], 0, 0, 0);
+                        for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[buf][mi], bl[buf][ni], acc[mi][ni], 0, 0, 0);
+                    }
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[buf][mi], bh[buf][ni], acc[mi][ni], 0, 0, 0);
                 }
@@ -1022,7 +1031,7 @@ static int launch_geo(const ConvK& k, const ConvGeo& g, int NI, int ck, dim3 gri
         if constexpr (KS == 3) { if (g.TW == 16) return launch_ni<PREC, CK0, KS, 2, 8, 16, 4, 1>(k, NI, grid, lds, s); }
         return launch_ni<PREC, CK0, KS, 2, 8, 8, 2, 1>(k, NI, grid, lds, s);
     }
-    if constexpr (PREC != CCDM_PREC_F32 && KS == 3) {
+    if constexpr (PREC == CCDM_PREC_F16X3 && KS == 3) {
         if (k.a.up == 2) {          // sub-pixel upsample conv: one n-tile (= phase x channel tile) per block
             if (g.TW == 16) hipLaunchKernelGGL((k_conv<PREC, CK0, 3, 1, 8, 16, 4, 1, 4, 1, true>), grid, dim3(256), lds, s, k);      // four phases per block
             else if (ck == 32) hipLaunchKernelGGL((k_conv<PREC, 32, 3, 1, 8, 8, 2, 1, 1, 1, true>), grid, dim3(128), lds, s, k);
@@ -1030,7 +1039,7 @@ static int launch_geo(const ConvK& k, const ConvGeo& g, int NI, int ck, dim3 gri
             return 0;
         }
     }
-    if constexpr (PREC != CCDM_PREC_F32 && KS == 3) {
+    if constexpr (PREC == CCDM_PREC_F16X3 && KS == 3) {
         if (g.TW == 32 && k.skip_wide) {          // fused 1x1 skip in 32-channel core-only chunks
             hipLaunchKernelGGL((k_conv<PREC, CK0, 3, 1, 8, 32, 4, 2, 1, 1, false, true>), grid, dim3(256), lds, s, k);
             return 0;
@@ -1133,7 +1142,7 @@ int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
     CCDM_REQUIRE(a.stride == 1 || a.ksize == 3, "conv: stride 2 is built for 3x3 only");
     CCDM_REQUIRE(a.C0 % 4 == 0 && a.C1 % 4 == 0 && C > 0, "conv: C0=%d C1=%d must be multiples of 4", a.C0, a.C1);
     CCDM_REQUIRE((a.C1 == 0) == (a.in1 == nullptr), "conv: in1/C1 mismatch");
-    CCDM_REQUIRE((a.prec & 255) == CCDM_PREC_F32 || (a.prec & 255) == CCDM_PREC_F16X3, "conv: precision %d not built", a.prec);
+    CCDM_REQUIRE((a.prec & 255) == CCDM_PREC_F32 || (a.prec & 255) == CCDM_PREC_F16X3 || (a.prec & 255) == CCDM_PREC_F16, "conv: precision %d not built", a.prec);
     if (a.stats0) {
         CCDM_REQUIRE(C % 32 == 0, "conv: GroupNorm(32, %d) needs C %% 32 == 0", C);
         CCDM_REQUIRE(C <= CCDM_MAX_CHANNELS, "conv: %d input channels > CCDM_MAX_CHANNELS", C);
@@ -1254,6 +1263,7 @@ int launch_conv(const ccdm_conv_args& a, hipStream_t s) {
 #endif
     dim3 grid(a.N * k.slices, k.ntiles / NI);
     const int rc = prec == CCDM_PREC_F32 ? launch_prec<CCDM_PREC_F32>(k, g, NI, ck, grid, lds, s)
+                   : prec == CCDM_PREC_F16 ? launch_prec<CCDM_PREC_F16>(k, g, NI, ck, grid, lds, s)
                                            : launch_prec<CCDM_PREC_F16X3>(k, g, NI, ck, grid, lds, s);
     if (rc) return rc;
     CCDM_CHECK_LAUNCH("conv");

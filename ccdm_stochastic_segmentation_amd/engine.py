@@ -124,6 +124,7 @@ class SamplerEngine:
               skip_src: Optional[Sequence[DevTensor]] = None, skip_key: Optional[str] = None) -> DevTensor:
         sd = self._sd
         prec = hip.PREC_F32 if wkey in self.f32_layers else self.prec
+        pack_prec = hip.PREC_F16X3 if prec == hip.PREC_F16 else prec        # the single-pass mode reads the hi halves of the F16X3 packing
         a, b = src[0], (src[1] if len(src) > 1 else None)
         cin = a.C + (b.C if b else 0)
         w = sd[wkey + ".weight"].numpy()
@@ -138,13 +139,13 @@ class SamplerEngine:
             # the 1x1 skip connection rides in the same GEMM: shared F16X3 exponents, biases pre-added
             ws = sd[skip_key + ".weight"].numpy().reshape(cout, -1)
             absmax = np.maximum(np.abs(w.reshape(cout, -1)).max(1), np.abs(ws).max(1)).astype(np.float32)
-            skip_w = self._upload(hip.pack_conv_weight(ws.reshape(cout, -1, 1, 1), 1, prec, absmax))
+            skip_w = self._upload(hip.pack_conv_weight(ws.reshape(cout, -1, 1, 1), 1, pack_prec, absmax))
             bias_np = bias_np + sd[skip_key + ".bias"].numpy()
         # Upsample + conv 3x3 runs in sub-pixel form (4 taps of the low-resolution input per output pixel instead of 9) where built
         subpixel = bool(up) and ksize == 3 and stride == 1 and resid is None and skip_src is None and gn is None and emb_off < 0 and \
             not _NO_SUBPIXEL and \
             bool(self.lib.ccdm_upconv_supported(cin, cout, prec))
-        wdev = self._upload(hip.pack_upconv_weight(w, prec) if subpixel else hip.pack_conv_weight(w, ksize, prec, absmax))
+        wdev = self._upload(hip.pack_upconv_weight(w, prec) if subpixel else hip.pack_conv_weight(w, ksize, pack_prec, absmax))
         bias = self._upload(bias_np)
         hin, win = a.h, a.w
         hc, wc = (2 * hin, 2 * win) if up else (hin, win)

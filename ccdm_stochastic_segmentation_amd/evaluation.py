@@ -131,15 +131,20 @@ def load_checkpoint(model, filename: str, key: str = "average_model", allow_pick
 def apply_sampler_options(model, params: dict) -> None:
     """Build-owned keys of the params file (absent in the reference's YAML, so an unchanged file runs the defaults):
          rng:  "philox" (default, device RNG) | "torch_cpu" (host generator in the reference's consumption order, parity mode)
-         prec: "f16x3" (default) | "f32" (exact-fp32 kernels)
+         prec: "f16x3" (default) | "f32" (exact-fp32 kernels) | "f16" (OPT-IN single-pass fast mode: operands rounded to fp16, outside
+               the 1e-4 parity contract — tools/fast_mode_report.py prints its error; logged as a warning)
          philox_seed, use_graph, substreams, on_range_error (layers | f32 | raise), f32_layers, slicing: DenoisingModel attributes of the
          same names."""
     from . import hip
     model.rng = str(params.get("rng", "philox"))
     prec = str(params.get("prec", "f16x3")).lower()
-    if prec not in ("f16x3", "f32"):
-        raise ValueError(f"prec: {prec!r} (expected 'f16x3' or 'f32')")
-    model.prec = hip.PREC_F32 if prec == "f32" else hip.PREC_F16X3
+    if prec not in ("f16x3", "f32", "f16"):
+        raise ValueError(f"prec: {prec!r} (expected 'f16x3', 'f32' or 'f16')")
+    if prec == "f16":
+        import logging
+        logging.getLogger(__name__).warning("prec: f16 — single-pass fp16 products (~2^-11 per operand): faster, NOT the reference's arithmetic "
+                                            "(outside the 1e-4 parity contract; see tools/fast_mode_report.py)")
+    model.prec = {"f32": hip.PREC_F32, "f16x3": hip.PREC_F16X3, "f16": hip.PREC_F16}[prec]
     model.philox_seed = int(params.get("philox_seed", 0))
     model.use_graph = bool(params.get("use_graph", True))
     model.substreams = int(params.get("substreams", 0))          # 0 = automatic (DenoisingModel)

@@ -30,6 +30,7 @@ ATTENTION_FORCE_VALU = 256          # bit 8 of ccdm_attention's `order`: the vec
 ATTENTION_VALU_WIDTHS = (4, 8, 12, 16, 24, 32, 48, 64)      # head widths that kernel is instantiated for
 DIAG_GENERAL_KERNEL = 2048 << 8     # CCDM_DIAG_GENERAL_KERNEL: OR into ConvArgs.prec to bypass the specialised conv kernels (parity tests)
 PREC_F32, PREC_F16X3 = 0, 1
+PREC_F16 = 2             # CCDM_PREC_F16: the OPT-IN single-pass fast mode (one fp16 MFMA per product, ~2^-11 per operand) — outside the parity contract
 STEP_SAMPLE, STEP_LAST_CONFIDENCE, STEP_LAST_MAJORITY, STEP_LAST_KEEP, STEP_SOFTMAX_ONLY = 0, 1, 2, 3, 4
 STATS_MAX_SLICES = 64       # CCDM_STATS_MAX_SLICES: what a GroupNorm consumer reads
 F16X3_LIMIT = 4094.0        # CCDM_F16X3_LIMIT: the fp16 split is exact for staged |a| below this

@@ -275,7 +275,9 @@ class DenoisingModel(nn.Module):
       consumes it (parity mode: seeded runs reproduce the reference's class indices; the host RNG is the bottleneck).
     `prec` selects the conv arithmetic: hip.PREC_F16X3 (default; fp16 hi/lo split x3 on the matrix cores, ~2^-22 per
     product, with the exact-fp32 kernel taking over any layer whose raw input leaves the split's range) or
-    hip.PREC_F32 (exact fp32 MFMA everywhere, the validation mode)."""
+    hip.PREC_F32 (exact fp32 MFMA everywhere, the validation mode).  hip.PREC_F16 is the OPT-IN single-pass fast mode (every conv on the
+    general kernel with one fp16 MFMA per product; attention cores keep the split): narrower arithmetic than the reference's, outside the
+    parity contract, never a default."""
 
     def __init__(self, diffusion: DiffusionModel, unet: UNetModel, dataset_file: str, step_T_sample: str = "majority"):
         super().__init__()

@@ -49,7 +49,10 @@ int ccdm_gn_stats(const float* x /*dev [N,HW,C]*/, int N, int HW, int C, int sli
  * ------------------------------------------------------------------------------------------------- */
 enum { CCDM_ACT_NONE = 0, CCDM_ACT_SILU = 1 };
 enum { CCDM_PREC_F32 = 0,      /* v_mfma_f32_32x32x2_f32: exact fp32 products and accumulation          */
-       CCDM_PREC_F16X3 = 1 };  /* fp16 hi/lo split, 3 x v_mfma_f32_32x32x16_f16, fp32 accumulate (~2^-22) */
+       CCDM_PREC_F16X3 = 1,    /* fp16 hi/lo split, 3 x v_mfma_f32_32x32x16_f16, fp32 accumulate (~2^-22) */
+       CCDM_PREC_F16 = 2 };    /* OPT-IN fast mode (ccdm_conv2d only; weights packed as for CCDM_PREC_F16X3): ONE fp16 MFMA per product — operands
+                                  rounded to fp16 (~2^-11 each), fp32 accumulate.  Narrower arithmetic than the reference's: outside the parity
+                                  contract, never a default, never the benchmarked configuration (tools/fast_mode_report.py prints its error) */
 /* Range of CCDM_PREC_F16X3: a staged activation a (after GroupNorm/SiLU, or the raw input where there is none) must satisfy
  * |a| < 4094.  Beyond that its fp16 hi half is infinite and every output the element reaches is NaN/Inf — never a silently
  * clipped number; the step epilogue (ccdm_post_args.range_flag) turns that into a sticky device flag the host checks.

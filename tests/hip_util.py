@@ -43,6 +43,9 @@ def conv2d(srcs, weight, bias, ksize, *, stats=None, gamma=None, beta=None, act=
     cout = w.shape[0]
     absmax = None
     bias = np.asarray(bias, dtype=np.float32)
+    conv_prec = prec
+    if prec == hip.PREC_F16:        # the opt-in single-pass mode reads the hi halves of the F16X3 packing
+        prec = hip.PREC_F16X3
     if skip is not None:            # (list of NHWC tensors, weight [Cout,Cs,1,1], bias): fused 1x1 skip connection
         ssrc, sw, sb = skip
         sw = np.ascontiguousarray(sw, dtype=np.float32).reshape(cout, -1)
@@ -71,7 +74,7 @@ def conv2d(srcs, weight, bias, ksize, *, stats=None, gamma=None, beta=None, act=
     args.eps, args.act = 1e-5, act
     args.N, args.Hin, args.Win, args.Hout, args.Wout = N, Hin, Win, Hout, Wout
     args.ksize, args.stride, args.up, args.fine_slices = ksize, stride, int(up), int(fine)      # fine: False / True (level 1) / 2
-    args.w, args.bias, args.Cout, args.prec = wdev.data_ptr(), bdev.data_ptr(), cout, prec | int(diag)      # diag: hip.DIAG_* bits
+    args.w, args.bias, args.Cout, args.prec = wdev.data_ptr(), bdev.data_ptr(), cout, conv_prec | int(diag)      # diag: hip.DIAG_* bits
     args.emb_off = -1
     table = emb if emb is not None else film
     if table is not None:

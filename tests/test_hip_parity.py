@@ -1003,6 +1003,40 @@ def test_forty_classes_against_the_reference(U, golden, parity_log):
             assert mism <= 2.0 / (N * H * W)
 
 
+def test_single_pass_fast_mode_is_opt_in_and_its_error_is_measured(U, golden, parity_log):
+    """prec = PREC_F16 (one fp16 MFMA per product, SURVEY section 7 hard part 1's opt-in mode): never a default; a conv layer within the
+    ~2^-11-per-operand bound that arithmetic implies; one LIDC U-Net step against the reference golden G4 — the error is logged (it is
+    OUTSIDE the 1e-4 contract by construction) and bounded well below anything that changes a class map on its own."""
+    model = build_model(250, "cosine", {"s": 0.008}, [(1, 128, 128), (2, 128, 128)], (1, 128, 128), "unet_openai", LIDC_BP,
+                        "datasets.lidc", "confidence", None)
+    assert model.prec == hip.PREC_F16X3                          # the default stays the split arithmetic
+    rng = np.random.default_rng(77)
+    x = rnd(rng, 2, 64, 32, 32)
+    w = rnd(rng, 64, 64, 3, 3) / np.sqrt(64 * 9)
+    b = rnd(rng, 64, scale=0.1)
+    gamma, beta = 1 + rnd(rng, 64, scale=0.2), rnd(rng, 64, scale=0.2)
+    ref = F.conv2d(F.silu(F.group_norm(x.double(), 32, gamma.double(), beta.double(), 1e-5)), w.double(), b.double(), padding=1)
+    xs = U.nhwc(x)
+    st = [U.gn_stats(xs, 1)]
+    out, _ = U.conv2d([xs], w.numpy(), b.numpy(), 3, stats=st, gamma=gamma.numpy(), beta=beta.numpy(), act=hip.ACT_SILU, prec=hip.PREC_F16)
+    err = (U.bchw(out).double() - ref).abs().max().item()
+    split, _ = U.conv2d([xs], w.numpy(), b.numpy(), 3, stats=st, gamma=gamma.numpy(), beta=beta.numpy(), act=hip.ACT_SILU, prec=hip.PREC_F16X3)
+    err3 = (U.bchw(split).double() - ref).abs().max().item()
+    assert err3 < 2e-5 and 1e-5 < err < 5e-3, (err3, err)       # ~2^-11 per operand over 576 products; the split mode is 200x closer
+    sd = {k: torch.from_numpy(v) for k, v in make_synthetic_state_dict(model.unet.spec, 0).items()}
+    model.unet.load_state_dict(sd, strict=True)
+    model = model.to("cuda:0").eval()
+    g = golden["g4_unet_step_lidc"]
+    r2 = np.random.default_rng(1234)
+    image = torch.from_numpy(r2.uniform(-1, 1, (2, 1, 128, 128)).astype(np.float32))
+    idx = torch.from_numpy(r2.integers(0, 2, (2, 128, 128)))
+    model.prec = hip.PREC_F16
+    out = model(O.one_hot_bchw(idx, 2).to(U.DEV), image.to(U.DEV), t=torch.full((2,), 37.0), validation=True)["diffusion_out"].cpu().numpy()
+    e = np.abs(out - g["out"])
+    parity_log("fast_mode_f16", conv_max_err=err, conv_max_err_split_mode=err3, unet_step_max_dp=e.max(), unet_step_median_dp=float(np.median(e)))
+    assert 1e-5 < e.max() < 2e-2 and (out.argmax(1) != g["out"].argmax(1)).mean() < 2e-3
+
+
 def test_philox_stream_matches_oracle(U):
     """Throughput-mode RNG: the device Philox4x32-10 stream equals the numpy restatement; indices equal
     argmax(P^/E) with the oracle's E wherever the race is not a last-ulp tie."""
