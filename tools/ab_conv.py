@@ -10,9 +10,10 @@ from ccdm_stochastic_segmentation_amd import hip
 if __name__ == "__main__":
     idx = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "0,1,6,10").split(",")]
     dbg = int(os.environ.get("DBG", "0"))
+    prec = int(os.environ.get("PREC", str(hip.PREC_F16X3)))          # 2: the opt-in single-pass mode (what the matrix work of a layer is worth)
     out = []
     for i in idx:
         sh = B.SHAPES[i]
-        ms = min(B.run(hip.PREC_F16X3, sh, dbg=dbg)[0] for _ in range(3))
+        ms = min(B.run(prec, sh, dbg=dbg)[0] for _ in range(3))
         out.append(f"{sh[1]+sh[2]}->{sh[3]}@{sh[4]} k{sh[6]}: {ms*1e3:.1f}")
-    print(os.environ.get("CCDM_LIB", "tree"), "dbg", dbg, " | ".join(out))
+    print(os.environ.get("CCDM_LIB", "tree"), "prec", prec, "dbg", dbg, " | ".join(out))
