@@ -468,7 +468,7 @@ def main():
                 sh["ops"].append(i)
             grid_threads = n * hip.load().ccdm_conv_slices(H, W, 1, 3) * 256
             traffic = traffic_note = None
-            if f16 and not args.no_pmc:
+            if f16 and not args.no_pmc and world == 1:          # (N > 1: the other ranks sit in the final barrier meanwhile — no child passes there)
                 traffic, traffic_note = measure_pmc_traffic(args, grid_threads, len(dom_ops))
             must_move = bytes_io / len(dom_ops)
             res["roofline"] = {
