@@ -1241,6 +1241,38 @@ def test_trajectory_three_classes_runs_the_fused_head_against_the_oracle(U, vote
         assert mism <= FREE_RUN_FRAC
 
 
+def test_full_t250_walk_against_the_oracle(U, parity_log):
+    """The headline configuration's loop end to end: ALL T = 250 denoise steps of the LIDC network, free-running, seeded (parity RNG: the
+    x_T draw and every per-step Exp(1) block from torch's CPU generator in the reference's order), against the oracle's
+    forward_denoising — 249 consecutive draws in which a flipped pixel would perturb everything after it."""
+    N, K = 1, 2
+    model = build_model(250, "cosine", {"s": 0.008}, [(1, 128, 128), (K, 128, 128)], (1, 128, 128), "unet_openai", LIDC_BP, "datasets.lidc", "confidence", None)
+    sd = {k: torch.from_numpy(v) for k, v in make_synthetic_state_dict(model.unet.spec, 0).items()}
+    model.unet.load_state_dict(sd, strict=True)
+    model = model.to("cuda:0").eval()
+    model.rng = "torch_cpu"
+    image = torch.from_numpy(np.random.default_rng(250).uniform(-1, 1, (N, 1, 128, 128)).astype(np.float32))
+    torch.manual_seed(250)
+    idx, _ = O.draw_x_T(N, K, 128, 128)
+    x = O.one_hot_bchw(idx, K)
+    torch.manual_seed(9)
+    out = model(x.to(U.DEV), image.to(U.DEV))["diffusion_out"].cpu()
+    torch.manual_seed(9)
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(min(16, nthr))         # (these small convs are > 10x slower on all 256 threads of the pool's hosts)
+    try:
+        ref = O.forward_denoising(sd, LIDC_CFG, O.make_schedule("cosine", 250, {"s": 0.008}), x, image, None, None, "confidence")["diffusion_out"]
+    finally:
+        torch.set_num_threads(nthr)
+    assert out.dtype == ref.dtype and out.shape == ref.shape
+    mism = (out.argmax(1) != ref.argmax(1)).float().mean().item()
+    err = (out - ref).abs()
+    frac = (err > 1e-3).float().mean().item()
+    print(f"T=250 free-running: class mismatch {mism:.2e}, max|dp| {err.max().item():.2e}, frac>1e-3 {frac:.2e}")
+    parity_log("full_t250_walk_vs_oracle", class_mismatch=mism, max_dp=err.max().item(), frac_gt_1e3=frac, median_dp=err.median().item())
+    assert err.median().item() < 1e-6 and mism <= 20 * FREE_RUN_FRAC and frac <= 20 * FREE_RUN_FRAC      # (250 steps of possible near-ties)
+
+
 def test_caller_contract_g9(U, golden, lidc_model):
     model, _ = lidc_model
     g = golden["g9_caller"]
