@@ -474,7 +474,7 @@ def main():
             res["roofline"] = {
                 "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 "traffic": traffic["bytes_per_launch"] if traffic else None,
-                "traffic_source": traffic_note if traffic else f"not measured in this run ({traffic_note or '--no-pmc'}); see traffic_offline",
+                "traffic_source": traffic_note if traffic else f"not measured in this run ({traffic_note or ('N > 1: the counter passes belong to the N = 1 line' if world > 1 else '--no-pmc')}); see traffic_offline",
                 "traffic_detail": traffic,
                 "traffic_offline": None if traffic else offline_pmc_traffic(args.config, grid_threads),
                 "must_move_bytes_per_launch": must_move,
