@@ -38,7 +38,9 @@ namespace ccdm {
 // (CCDM_ABLATION=1 python -c "from ccdm_stochastic_segmentation_amd import hip; hip.build()"): as run-time tests they put
 // a branch around every store and every phase of the production kernel.
 //   1 no MFMA | 2 no commit | 4 no loads | 8 no stores | 16 phase timeline | 32 no weight-fragment staging (wrong results: what
-//   removing the global -> registers -> LDS round trip of the B chunk could buy) | 256 no barriers (wrong results)
+//   removing the global -> registers -> LDS round trip of the B chunk could buy) | 64 no halo (every halo request is pointed at the
+//   nearest CORE pixel of its tile — wrong results: what the tile's halo rows / columns cost in fetched bytes and time) |
+//   256 no barriers (wrong results)
 //   512 / 1024: pad the LDS request so that at most 2 / 1 blocks fit a CU (host side, always available)
 #ifdef CCDM_ABLATION
 #define CCDM_DBG(bit) ((dbg & (bit)) != 0)
@@ -299,7 +301,7 @@ __global__ __launch_bounds__(WAVES * KSP * 64, min_waves(MI, NI, PREC, CKT, WAVE
                 return;
             }
         }
-        const bool skseg = KS > 1 && ch >= nchunk_main;           // uniform: skip-segment chunk (1x1, no halo needed)
+        const bool skseg = KS > 1 && (ch >= nchunk_main || CCDM_DBG(64));   // uniform: skip-segment chunk (1x1, no halo needed)
         const int ylo = skseg ? min(oy0, Hc - 1) : 0, yhi = skseg ? min(oy0 + TH - 1, Hc - 1) : Hc - 1;
         const int xlo = skseg ? min(ox0, Wc - 1) : 0, xhi = skseg ? min(ox0 + TW - 1, Wc - 1) : Wc - 1;
         // Every load is issued unconditionally with its address clamped into the tensor; padding is zeroed at commit.

@@ -57,15 +57,24 @@ class TestLIDC(torch.utils.data.Dataset):
     """`Test_LIDC` + `batch_transform` of the reference (datasets/lidc.py:164-198): image*2 -> [-1,1]; labels
     [4,2,128,128] one-hot; uniform annotator weights.  `source` is the path of `data_lidc.hdf5` (read with h5py) or any
     mapping with the file's layout: source[split]["images"][i] -> [128,128] float, source[split]["labels"][i] -> [4,128,128]
-    integer.  `max_size` follows `test_dataset(max_size)` (datasets/lidc.py:201-210): None = the whole split, else the
+    integer.  A path ending in `.npz` is read with numpy as a mirror of the HDF5 file (arrays named "<split>/images" and
+    "<split>/labels": `tools/lidc_hdf5_to_npz.py` writes one where h5py exists) — the file form that runs on hosts without h5py.
+    `max_size` follows `test_dataset(max_size)` (datasets/lidc.py:201-210): None = the whole split, else the
     first max_size items (the reference's Subset(range(max_size)) fails when the split is smaller; here it is capped)."""
 
     def __init__(self, source, split: str = "test", max_size: Optional[int] = None):
-        if isinstance(source, (str, os.PathLike)):
+        if isinstance(source, (str, os.PathLike)) and str(source).endswith(".npz"):
+            arrays = np.load(source)
+            missing = [k for k in (f"{split}/images", f"{split}/labels") if k not in arrays.files]
+            if missing:
+                raise KeyError(f"{source}: no array named {missing[0]!r} (an .npz mirror of data_lidc.hdf5 holds '<split>/images' and '<split>/labels')")
+            source = {split: {"images": arrays[f"{split}/images"], "labels": arrays[f"{split}/labels"]}}
+        elif isinstance(source, (str, os.PathLike)):
             try:
                 import h5py
             except ImportError as e:
-                raise ImportError("reading data_lidc.hdf5 needs h5py, which is not installed in this image") from e
+                raise ImportError("reading data_lidc.hdf5 needs h5py (README.md, requirements), which is not installed here; "
+                                  "tools/lidc_hdf5_to_npz.py writes an .npz mirror this reader takes without it") from e
             source = h5py.File(source, "r")
         self.ds = source[split]
         self.n = len(self.ds["images"]) if max_size is None else min(int(max_size), len(self.ds["images"]))

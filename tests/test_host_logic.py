@@ -366,10 +366,20 @@ def test_lidc_reader_layout_and_transform(tmp_path):
     import yaml
     p = yaml.safe_load(open(os.path.join(ROOT, "params_eval.yml")))
     assert p["dataset_val_max_size"] is None
+    # file form 1 (runs everywhere): the .npz mirror of the HDF5 layout, through make_dataset like a params file would name it
+    fz = tmp_path / "data_lidc.npz"
+    np.savez(fz, **{"test/images": images, "test/labels": labels, "val/images": images[:1], "val/labels": labels[:1]})
+    dz = E.make_dataset({"dataset_file": "datasets.lidc", "dataset_path": str(fz), "dataset_val_max_size": 4})
+    assert len(dz) == 4 and torch.equal(dz[2][0], img) and torch.equal(dz[2][1], lab)
+    with pytest.raises(KeyError, match="train/images"):
+        E.TestLIDC(str(fz), "train", None)
+    # file form 2: a real HDF5 file — needs h5py (README.md lists it); where h5py exists this leg runs and must pass
     try:
         import h5py
     except ImportError:
-        pytest.skip("h5py is not installed in this image: the HDF5 file form of the reader cannot run here")
+        with pytest.raises(ImportError, match="h5py"):
+            E.TestLIDC(str(tmp_path / "data_lidc.hdf5"), "test", None)
+        pytest.skip("h5py is not installed in this image: the HDF5 leg of the reader cannot run here (the .npz leg above did)")
     f = tmp_path / "data_lidc.hdf5"
     with h5py.File(f, "w") as h:
         gtest = h.create_group("test")

@@ -137,6 +137,10 @@ if __name__ == "__main__":
         for i in [int(v) for v in os.environ.get("TIMELINE", "0").split(",")]:
             print(SHAPES[i]); timeline_pc(precs[0], SHAPES[i])
         sys.exit(0)
+    if os.environ.get("PMCRUN"):          # one (shape, ablation bits) pair, a few launches: the unit tools/pmc_traffic.sh counts
+        i, d = [int(v) for v in os.environ["PMCRUN"].split(",")]
+        print(SHAPES[i], "dbg", d, run(precs[0], SHAPES[i], iters=5, dbg=d))
+        sys.exit(0)
     if os.environ.get("TIMELINE"):
         for i in [int(v) for v in os.environ["TIMELINE"].split(",")]:
             print(SHAPES[i]); timeline(precs[0], SHAPES[i])
