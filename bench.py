@@ -130,10 +130,22 @@ def cpu_baseline(sd, image4, cfg, cfg_name, seed=0, budget_s=30.0):
     return res
 
 
+def _run_ranks(cmd, env):
+    """Run the N-rank job: (rc, tail of its stderr).  stdout passes through (rank 0's JSON line), stderr is echoed and kept — the retry
+    decision of self_launch reads it."""
+    p = subprocess.Popen(cmd, env=env, stderr=subprocess.PIPE, text=True)
+    tail = []
+    for line in p.stderr:
+        sys.stderr.write(line)
+        tail.append(line)
+        del tail[:-200]
+    return p.wait(), "".join(tail)
+
+
 def self_launch(args) -> int:
     """`python bench.py --gpus N` without a launcher: start N ranks of this script with torch.distributed.run.  The ranks need dmabuf IPC
     (HSA_ENABLE_IPC_MODE_LEGACY=0, exported on these boxes); where this process had to set it itself and the job fails, the job is
-    started ONCE more without the override, saying so."""
+    started ONCE more without the override, saying so — only when its stderr names IPC / RCCL (any other failure is returned as it is)."""
     import socket
 
     def launch(env):
@@ -142,19 +154,23 @@ def self_launch(args) -> int:
             port = s.getsockname()[1]
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        return subprocess.call(cmd, env=env)
+        return _run_ranks(cmd, env)
 
     env = dict(os.environ)
     set_here = "HSA_ENABLE_IPC_MODE_LEGACY" not in env
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # the host driver supports dmabuf IPC only (RCCL needs it)
     env["CCDM_BENCH_CHILD"] = "1"
-    rc = launch(env)
-    if rc != 0 and set_here:
-        print(f"bench.py: the {args.gpus}-rank job failed (rc {rc}) with HSA_ENABLE_IPC_MODE_LEGACY=0 set by bench.py; retrying once without it",
+    rc, err = launch(env)
+    ipc_like = any(w in err for w in ("hipIpc", "IPC", "ipc", "NCCL", "RCCL", "nccl", "rccl", "dmabuf"))
+    if rc != 0 and set_here and ipc_like:
+        print(f"bench.py: the {args.gpus}-rank job failed (rc {rc}) with an IPC / RCCL error while HSA_ENABLE_IPC_MODE_LEGACY=0 was set by bench.py; "
+              f"retrying once without it",
               file=sys.stderr, flush=True)
         env.pop("HSA_ENABLE_IPC_MODE_LEGACY")
         env["CCDM_NO_HSA_IPC_OVERRIDE"] = "1"
-        rc = launch(env)
+        rc2, _ = launch(env)
+        print(f"bench.py: first attempt rc {rc}, retry rc {rc2}", file=sys.stderr, flush=True)
+        rc = rc2
     return rc
 
 
@@ -203,9 +219,11 @@ def measure_pmc_traffic(args, grid_threads: int, launches_per_dstep: int, dsteps
     per = {}
     t_all = time.perf_counter()
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES"):
             d = os.path.join(tmp, counter)
-            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+            # (the matrix-pipe pass carries GRBM_GUI_ACTIVE beside it — another counter block, same pass — as its denominator)
+            pmc = [counter] + (["GRBM_GUI_ACTIVE"] if counter.startswith("SQ_") else [])
+            cmd = [exe, "--pmc", *pmc, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
                    "--config", args.config, "--denoise-steps", str(dsteps), "--steps", "1", "--warmup", "1", "--graph", "0", "--substreams", "1",
                    "--no-cpu-baseline", "--no-secondary", "--prec", args.prec, "--slicing", args.slicing] + (["--batch", str(args.batch)] if args.batch else [])
             try:
@@ -218,31 +236,43 @@ def measure_pmc_traffic(args, grid_threads: int, launches_per_dstep: int, dsteps
             rows = {}
             for f in files:
                 for row in csv.DictReader(open(f)):
-                    if row["Counter_Name"] != counter or "ccdm::k_conv<" not in row["Kernel_Name"] or int(row["Grid_Size"]) != grid_threads:
+                    if "ccdm::k_conv<" not in row["Kernel_Name"] or int(row["Grid_Size"]) != grid_threads:
                         continue
-                    e = rows.setdefault(row["Kernel_Name"], [0, 0.0, 0.0])
+                    e = rows.setdefault(row["Kernel_Name"], [0, 0.0, 0.0, 0.0])
+                    if row["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                        e[3] += float(row["Counter_Value"])
+                        continue
+                    if row["Counter_Name"] != counter:
+                        continue
                     e[0] += 1
                     e[1] += float(row["Counter_Value"])
                     e[2] += (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3
             if not rows:
                 return None, f"no conv kernel on a grid of {grid_threads} threads in the {counter} pass"
             name = max(rows, key=lambda k: rows[k][2])
-            cnt, tot, us = rows[name]
+            cnt, tot, us, gui = rows[name]
             if cnt != launches_per_dstep * executions:
                 return None, (f"{counter} pass: the longest-running conv symbol on that grid was launched {cnt} times, expected {launches_per_dstep} x {executions} "
                               f"({name[:120]}): the dominant class is not what bench.py assumes")
-            per[counter] = (name, tot / cnt, us / cnt, cnt)
+            per[counter] = (name, tot / cnt, us / cnt, cnt, gui / cnt)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    if per["FETCH_SIZE"][0] != per["WRITE_SIZE"][0]:
-        return None, "the two passes disagree on the dominant symbol"
+    if len({v[0] for v in per.values()}) != 1:
+        return None, "the counter passes disagree on the dominant symbol"
     rd, wr = 2.0 * per["FETCH_SIZE"][1] * 1024.0, per["WRITE_SIZE"][1] * 1024.0
+    # SQ_VALU_MFMA_BUSY_CYCLES: cycles summed over the chip's 1024 SIMDs; GRBM_GUI_ACTIVE: busy cycles summed over the 8 XCDs, so one
+    # launch offers GRBM_GUI_ACTIVE / 8 x 1024 SIMD-cycles (tools/pmc_bench_summary.py uses the same rule)
+    mf = per["SQ_VALU_MFMA_BUSY_CYCLES"]
+    mfma_busy = mf[1] / (mf[4] / 8.0 * 1024.0) if mf[4] > 0 else None
     import re
     return ({"bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr, "launches_counted": per["FETCH_SIZE"][3],
              "kernel": re.sub(r"\(.*", "", per["FETCH_SIZE"][0].replace("void ", "")), "avg_launch_us_under_counters": per["FETCH_SIZE"][2],
+             "mfma_busy": mfma_busy, "mfma_busy_cycles_per_launch": mf[1], "gui_active_cycles_per_launch": mf[4],
              "seconds_spent": time.perf_counter() - t_all},
-            f"measured in this run: two child passes of this bench command under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE ({dsteps}-step strided walk, one "
-            f"stream, eager launches); FETCH_SIZE x 2 (gfx950 wide-read correction) + WRITE_SIZE, KiB -> bytes, mean over the class's launches")
+            f"measured in this run: three child passes of this bench command under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc "
+            f"SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE ({dsteps}-step strided walk, one stream, eager launches); FETCH_SIZE x 2 (gfx950 wide-read "
+            f"correction: the L2 fetches whole 128-byte lines and tallies them at 64 B — calibrated on this kernel's own access pattern, "
+            f"profiles/r06_dominant_traffic_decomposition.json) + WRITE_SIZE, KiB -> bytes, mean over the class's launches")
 
 
 def main():
@@ -274,6 +304,11 @@ def main():
                                                           "N-rank job equals the same shard sampled alone)")
     ap.add_argument("--emulate-rank", default="", metavar="R/W", help="one process plays rank R of a W-rank job (its inputs, its Philox sample "
                                                                      "offset), without a process group: the single-process side of the shard test")
+    ap.add_argument("--ref-value", type=float, default=0.0, help="samples/s of the N = 1 line of the same bench (BENCH-style): the N > 1 line then carries "
+                                                                 "weak_scaling_efficiency = value_N / (N x ref)")
+    ap.add_argument("--secondary", action="store_true", help="N > 1 only: run rank 0's untimed secondary pass (roofline taps, per-stage table) although the "
+                                                             "other ranks wait in the final barrier meanwhile (default at N > 1: skipped; at N = 1 it always runs "
+                                                             "unless --no-secondary)")
     ap.add_argument("--cpu-probe", type=int, default=0, help=argparse.SUPPRESS)      # child mode of cpu_baseline's all-cores probe
     args = ap.parse_args()
     if args.cpu_probe:
@@ -316,6 +351,8 @@ def main():
         model.use_graph = bool(args.graph)
     if args.substreams >= 0:
         model.substreams = args.substreams
+    if args.graph >= 0 or args.substreams > 0:
+        model.calibrate_mode = False                                # an explicit mode is taken as given (the default measures the modes once, in the warm-up)
     model.sample_offset = play_rank * n                           # Philox counters keyed by global sample index
     model.slicing = args.slicing
     use_graph, substreams = bool(model.use_graph), int(model.substreams)
@@ -366,6 +403,9 @@ def main():
         dist_barrier()
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if model.last_mode is not None:                                 # what the timed passes ran: the measured choice among the bit-identical modes
+        nsub, use_graph = int(model.last_mode[0]), bool(model.last_mode[1])
+    mode_choice = next(iter(model.mode_choice.values()), None)
     per_rank = None
     digest = None
     if args.digest:
@@ -383,7 +423,10 @@ def main():
         blobs = [torch.empty_like(blob) for _ in range(world)]
         dist.all_gather(blobs, blob)
         per_rank = [dict({"rank": r, "pass_s": float(v[0]) / max(args.steps, 1), "sampling_s": float(v[0] - v[1]) / max(args.steps, 1),
-                          "gather_s": float(v[1]) / max(args.steps, 1)}, **json.loads(bytes(b.tolist()).rstrip(b"\0").decode()))
+                          "gather_s": float(v[1]) / max(args.steps, 1),
+                          "ms_per_denoise_step": float(v[0] - v[1]) / max(args.steps, 1) / n_dsteps * 1e3,      # this rank's sampling alone (no gather)
+                          "samples_per_s": n * max(args.steps, 1) / max(float(v[0]), 1e-12)},
+                         **json.loads(bytes(b.tolist()).rstrip(b"\0").decode()))
                     for r, (v, b) in enumerate(zip(allr, blobs))]
         dt = max(float(v[0]) for v in allr)
     assert torch.isfinite(out).all()
@@ -404,11 +447,19 @@ def main():
                                    f"{'device Philox RNG' if args.rng == 'philox' else 'host torch-CPU Exp(1) noise over PCIe (parity mode)'}, random-init weights",
                        "name": args.config, "global_batch": n * world, "time_steps": T, "denoise_steps_run": n_dsteps,
                        "parallelism": f"batch-shard x{world}", "launch": "hip-graph" if use_graph else "eager", "substreams": nsub,
-                       "slicing": args.slicing},
+                       "slicing": args.slicing,
+                       "mode": ("measured in the warm-up: fastest of the bit-identical execution modes on this box (DenoisingModel.calibrate_mode)"
+                                if mode_choice is not None else "as configured"),
+                       "mode_ms_per_denoise_step": mode_choice["ms_per_denoise_step"] if mode_choice is not None else None},
         }
         if per_rank is not None:
             res["per_rank"] = per_rank
-            res["distributed"] = backend_info()
+            res["distributed"] = backend_info()            # backend, RCCL / HIP versions, IPC mode, RCCL probe: first collective (communicator setup) and steady all_reduce latency
+            res["slowest_rank"] = max(per_rank, key=lambda r: r["pass_s"])["rank"]
+            res["gather_share_of_pass"] = max(r["gather_s"] for r in per_rank) / max(dt / max(args.steps, 1), 1e-12)
+        if args.ref_value > 0:
+            res["weak_scaling_efficiency"] = res["value"] / (world * args.ref_value)
+            res["weak_scaling_ref_value"] = args.ref_value
         elif digest is not None:
             res["out_sha256"] = digest
         if args.emulate_rank:
@@ -470,7 +521,9 @@ def main():
             traffic = traffic_note = None
             if f16 and not args.no_pmc and world == 1:          # (N > 1: the other ranks sit in the final barrier meanwhile — no child passes there)
                 traffic, traffic_note = measure_pmc_traffic(args, grid_threads, len(dom_ops))
-            must_move = bytes_io / len(dom_ops)
+            # what a launch of the class HAS to move: conv input + output + weights + the identity-residual read of a ResBlock's second
+            # conv (round 5 left that read out: 326 instead of 364 MB at C2)
+            must_move = (bytes_io + sum(info[i].get("resid_bytes", 0) * n for i in dom_ops)) / len(dom_ops)
             res["roofline"] = {
                 "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 "traffic": traffic["bytes_per_launch"] if traffic else None,
@@ -479,7 +532,8 @@ def main():
                 "traffic_offline": None if traffic else offline_pmc_traffic(args.config, grid_threads),
                 "must_move_bytes_per_launch": must_move,
                 "frac_vs_must_move": (traffic["bytes_per_launch"] / must_move) if traffic else None,
-                "frac_vs_must_move_note": "HBM bytes the counters saw per launch over the bytes that must move (conv input + output + weights, no GroupNorm-read credit)",
+                "frac_vs_must_move_note": "bytes the L2's memory-side counters saw per launch over the bytes that must move (conv input + output + weights + the residual read of "
+                                          "a ResBlock's second conv; no GroupNorm-read credit).  FETCH_SIZE counts Infinity-Cache hits too: an upper bound on HBM bytes",
                 "note": tap_note,
                 "kernel": f"ccdm::k_conv<F16X3,16,3,1,8,32,4,2,1,1> (<PREC,CK,KS,STRIDE,TH,TW,WAVES,MI,NI,KSP>): every 3x3 stride-1 conv of the {H}x{W} stage "
                           f"(engine ops {dom_ops}), GN+SiLU on load" if f16 else f"ccdm::k_conv<F32,...> every 3x3 stride-1 conv of the {H}x{W} stage (engine ops {dom_ops})",
@@ -488,12 +542,16 @@ def main():
                 "achieved_conv_io_only": bytes_io / (tot_ms * 1e-3) / 1e9, "frac_conv_io_only": bytes_io / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "share_of_denoise_step": tot_ms / max(step_ms_tapped, 1e-9),
                 "algorithmic_tflops": flop / (tot_ms * 1e-3) / 1e12,
-                # matrix-pipe utilisation from the instruction count: every fp32 product is 3 fp16 MFMA products (hi*hi, hi*lo, lo*hi);
-                # relative to the dense fp16 peak at the top clock (the PMC figure SQ_VALU_MFMA_BUSY_CYCLES is in profiles/)
-                "mfma_util": (3.0 if f16 else 16.0) * flop / (tot_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
-                "mfma_util_source": "analytic: MFMA FLOPs issued (3 fp16 products per fp32 product) / HIP-event duration / 2.5 PFLOP/s dense "
+                # matrix-pipe utilisation: the COUNTER when this run measured it (SQ_VALU_MFMA_BUSY_CYCLES over the SIMD-cycles the launch
+                # offered), else the instruction count (every fp32 product is 3 fp16 MFMA products) against the dense fp16 peak at the top clock
+                "mfma_util": traffic["mfma_busy"] if traffic and traffic.get("mfma_busy") is not None else
+                             (3.0 if f16 else 16.0) * flop / (tot_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
+                "mfma_util_analytic": (3.0 if f16 else 16.0) * flop / (tot_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
+                "mfma_util_source": ("counter: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) of this run's PMC pass, mean over the class's launches; "
+                                     if traffic and traffic.get("mfma_busy") is not None else "analytic (no counter pass in this run); ") +
+                                    "mfma_util_analytic = MFMA FLOPs issued (3 fp16 products per fp32 product) / HIP-event duration / 2.5 PFLOP/s dense "
                                     "(tools/ubench/mfma_chain.hip: with random-mantissa operands the matrix pipe sustains 1.73 PFLOP/s — its clock is "
-                                    "data-dependent; against that rate the figure is x1.45)",
+                                    "data-dependent; against that rate the analytic figure is x1.45)",
             }
             res["roofline_shapes"] = {
                 k_: {"launches_per_denoise_step": v["launches_per_denoise_step"], "avg_launch_ms": v["ms"] / v["launches_per_denoise_step"],
@@ -545,7 +603,11 @@ def main():
                                 "note": "same workload on one stream (substreams = 1), same launch mode: secondary figure"}
         model.substreams = substreams
 
-    if rank == 0 and not args.no_secondary:
+    # N > 1: the untimed extras are opt-IN (--secondary) — while rank 0 runs them (about a minute) the other ranks sit in the final barrier,
+    # under RCCL's watchdog; the roofline objects belong to the N = 1 line anyway
+    if rank == 0 and res is not None and world > 1 and not args.secondary:
+        res["secondary_note"] = "N > 1: rank 0's untimed roofline / per-stage pass skipped (pass --secondary to run it); those objects are on the N = 1 line"
+    if rank == 0 and not args.no_secondary and (world == 1 or args.secondary):
         if world == 1:
             secondary()
         else:                                                      # the N-rank line must not die on an untimed extra
@@ -559,6 +621,10 @@ def main():
         print(json.dumps(res))
     if world > 1:
         dist_barrier()
+        from ccdm_stochastic_segmentation_amd.distributed import rccl_hung
+        if rccl_hung():                                            # this rank's RCCL probe thread never returned: tearing the group down would block on it
+            sys.stdout.flush()
+            os._exit(0)
         dist.destroy_process_group()
 
 

@@ -1080,11 +1080,11 @@ static int launch_prec(const ConvK& k, const ConvGeo& g, int NI, int ck, dim3 gr
 #endif
 }
 
-static int conv_slices_default(int tiles, bool up2);
+static int conv_slices_default(int tiles, bool up2, int stride);
 int conv_slices(int Hout, int Wout, int stride, bool up2 = false, int fine = 0) {
     const ConvGeo g = conv_geo(Hout, Wout, stride, up2, fine != 0);
     const int tiles = cdiv(Hout, g.TH) * cdiv(Wout, g.TW);
-    const int dflt = conv_slices_default(tiles, up2);
+    const int dflt = conv_slices_default(tiles, up2, stride);
     // latency slicing (ccdm_conv_args.fine_slices): up to CCDM_STATS_MAX_SLICES one- or two-tile workgroups per sample.  Measured on
     // the LIDC step: batch 8 2.06 -> 1.73 ms per denoise step, batch 64 3.32 -> 3.49 (every block prologue is paid per 2 tiles
     // instead of per 5.3) — hence a mode, not the rule.
@@ -1093,7 +1093,7 @@ int conv_slices(int Hout, int Wout, int stride, bool up2 = false, int fine = 0) 
     if (fine) { const int cap = fine >= 2 ? CCDM_STATS_MAX_SLICES : 32; const int f = tiles < cap ? tiles : cap; return f > dflt ? f : dflt; }
     return dflt;
 }
-static int conv_slices_default(int tiles, bool up2) {
+static int conv_slices_default(int tiles, bool up2, int stride) {
     // 12 slices for 128x128: with 3 resident blocks per CU, 64 samples x 12 slices = 768 blocks fill the 256 CUs
     // in exactly one round (5.3 tiles per block).  Larger images keep that work per block — one slice per 5.3 tiles (256x512:
     // 96, 512x1024: 384) — so a Cityscapes-sized batch of 4-16 samples still fills the chip (at 12 slices, 4 samples were
@@ -1106,6 +1106,12 @@ static int conv_slices_default(int tiles, bool up2) {
     // batches of 4-16 samples: one slice per tile / per four tiles there (C5 shard 14.26 -> 13.24 ms, C4 7.13 -> 6.84 ms per step)
     // (not for the sub-pixel upsample form, whose 8x16 tiling gives LIDC's 64x64 input the same 32 tiles at batch 64)
     if (!up2 && tiles >= 128 && tiles < 256) return 32;
+#ifndef CCDM_NO_S2_SLICES
+    // stride-2 convs of a 32-tile output (LIDC's Downsample 128x128 -> 64x64 on 8x16 tiles): one slice per FOUR tiles.  The rule below
+    // was made for Cityscapes batches of 4-16; at LIDC's batch its 2048 one-tile blocks were four rounds of 512 resident blocks, each
+    // paying the block prologue for one tile (round 6: 59 -> 5x us).  Still a function of the layer's shape only.
+    if (!up2 && stride == 2 && tiles == 32) return 8;
+#endif
     if (!up2 && tiles >= 24 && tiles < 48) return tiles < 32 ? tiles : 32;
     if (tiles >= 128) return tiles / 16 * 3;
     if (tiles >= 48) return 12;

@@ -1,4 +1,6 @@
-// Upsample (nearest x2) + conv 3x3 in sub-pixel form for the LOW-RESOLUTION decoder levels (inputs of at most 32x32 pixels), F16X3:
+// Upsample (nearest x2) + conv 3x3 in sub-pixel form, F16X3 — built for the low-resolution decoder levels, taken (upconv_eligible) by EVERY
+// Upsample conv of 32 / 64 / 96 / 128 input channels whose input tiles exactly (whole 8x16 tiles, or 8x8 tiles for 8-pixel-wide inputs),
+// whatever its size (tested up to 128x256 inputs):
 //
 //     out(2y+dy, 2x+dx) = sum_{a,b in {0,1}} W'[dy,dx][a,b] . in(y+dy-1+a, x+dx-1+b)            unet.py:106-116, include/ccdm_hip.h `up = 2`
 //
@@ -15,10 +17,13 @@
 //     it from (two requests ahead): no LDS staging of B, no barrier for it, 12 matrix instructions per 2 KB fragment pair.
 //   * the halo tile (10 x 18 pixels) is staged ONCE per tile with ALL input channels (raw input: x 2^4, fp16 hi/lo split, pitch 4 C + 16
 //     bytes: conflict-free 16-byte fragment reads for C in {32, 64, 96, 128}): one barrier in front of the matrix phase;
-//   * a block may walk several 32-channel output tiles from one staged tile (ctb: a partitioning choice only).
-// Same products in the same order as the general kernel's form (k-step outer, window tap inner; lo*hi, hi*lo, hi*hi): identical outputs
-// (tested bit for bit through CCDM_DIAG_GENERAL_KERNEL); the output statistics are one partial per (sample, slice) like its, the four
-// phases folded in phase order.
+//   * a block may walk several 32-channel output tiles from one staged tile (ctb — chosen from the BLOCK COUNT, i.e. from N too: a
+//     partitioning choice only, every output element is computed by the same instruction sequence either way);
+//   * C = 128 without aliasing the epilogue buffer onto the tile needs ~113 KB of LDS: one block per CU there.
+// Same products in the same order as the general kernel's form (k-step outer, window tap inner; lo*hi, hi*lo, hi*hi): identical OUTPUTS
+// (tested bit for bit through CCDM_DIAG_GENERAL_KERNEL).  The output statistics are one partial per (sample, slice) like the general
+// kernel's with the four phases folded in phase order, but accumulated per lane in another order: equal to fp32 rounding of the lane
+// sums (tested on the slice-summed partials at rtol 1e-6), not bit for bit.
 #include "ccdm_common.h"
 #include "ccdm_conv_common.h"
 

@@ -23,7 +23,45 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 # what init_from_env brought up: "nccl" (= RCCL; CPU tensors of the same group travel over gloo), "gloo", or None (group made elsewhere)
-_STATE = {"backend": None, "data_via_host": False, "rccl_error": None, "hsa_ipc_legacy_set_here": False}
+_STATE = {"backend": None, "data_via_host": False, "rccl_error": None, "hsa_ipc_legacy_set_here": False,
+          "rccl_probe_first_ms": None, "rccl_probe_ms": None, "rccl_hung": False}
+
+
+def _probe_rccl(local_rank: int, world: int, timeout_s: float):
+    """The first device collective (RCCL builds its communicator there) and a second one (its steady-state latency), in a daemon
+    thread the caller waits for at most `timeout_s`: a communicator that fails on ONE rank only leaves the other ranks blocked inside
+    the collective — they must still reach the gloo flag exchange.  Returns (error | None, first ms, steady ms, hung)."""
+    import threading
+    import time
+    box = {"err": None, "first": None, "steady": None, "done": False}
+
+    def run():
+        try:
+            torch.cuda.set_device(local_rank)
+            probe = torch.ones(1, device=torch.device("cuda", local_rank))
+            t0 = time.perf_counter()
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+            box["first"] = (time.perf_counter() - t0) * 1e3
+            if int(probe.item()) != world:
+                box["err"] = f"RCCL all_reduce of ones over {world} ranks returned {probe.item()}"
+            else:
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    dist.all_reduce(probe)
+                torch.cuda.synchronize()
+                box["steady"] = (time.perf_counter() - t0) * 1e3 / 5
+        except Exception as e:       # noqa: BLE001   (RCCL reports through RuntimeError / DistBackendError)
+            box["err"] = f"{type(e).__name__}: {e}"
+        box["done"] = True
+
+    th = threading.Thread(target=run, name="ccdm-rccl-probe", daemon=True)
+    th.start()
+    th.join(timeout_s)
+    if not box["done"]:
+        return (f"the first RCCL collective did not return within {timeout_s:.0f} s on this rank (another rank's communicator probably "
+                f"failed): treated as an RCCL failure"), None, None, True
+    return box["err"], box["first"], box["steady"], False
 
 
 def init_from_env(backend: Optional[str] = None, force: bool = False) -> Tuple[int, int, int]:
@@ -33,7 +71,11 @@ def init_from_env(backend: Optional[str] = None, force: bool = False) -> Tuple[i
     gloo.  RCCL builds its communicator at the first device collective, so that collective is issued HERE, on one element; if it
     raises on any rank, every rank learns it over gloo, the RCCL error is printed with the versions and the IPC setting, and the
     path's one exchange (the final gather) travels through the host instead — loudly (`backend_info()` says so, bench.py puts it
-    in its JSON line): a sampling job whose only collective is one gather should not die because peer-to-peer IPC is unavailable."""
+    in its JSON line): a sampling job whose only collective is one gather should not die because peer-to-peer IPC is unavailable.
+    The probe runs in a monitored thread (CCDM_RCCL_PROBE_TIMEOUT_S, default 60 s): when the communicator fails on ONE rank only, the
+    other ranks sit inside the collective — after the timeout they count as failed too and join the flag exchange.  Their probe
+    threads stay blocked in RCCL, so such a process must not call destroy_process_group (`rccl_hung()`: bench.py exits without it).
+    A rank that dies outright (no exception, no timeout) still takes the job down with gloo's own timeout: that is not recoverable here."""
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -50,15 +92,8 @@ def init_from_env(backend: Optional[str] = None, force: bool = False) -> Tuple[i
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="cpu:gloo,cuda:nccl", rank=rank, world_size=world)
             _STATE["backend"] = "nccl"
-            err = None
-            try:
-                probe = torch.ones(1, device=torch.device("cuda", local_rank))
-                dist.all_reduce(probe)
-                torch.cuda.synchronize()
-                if int(probe.item()) != world:
-                    err = f"RCCL all_reduce of ones over {world} ranks returned {probe.item()}"
-            except Exception as e:       # noqa: BLE001   (RCCL reports through RuntimeError / DistBackendError)
-                err = f"{type(e).__name__}: {e}"
+            err, first_ms, steady_ms, hung = _probe_rccl(local_rank, world, float(os.environ.get("CCDM_RCCL_PROBE_TIMEOUT_S", "60")))
+            _STATE["rccl_probe_first_ms"], _STATE["rccl_probe_ms"], _STATE["rccl_hung"] = first_ms, steady_ms, hung
             flag = torch.tensor([0 if err is None else 1], dtype=torch.int32)
             dist.all_reduce(flag)                                    # host tensor: gloo
             if int(flag.item()) != 0:
@@ -94,10 +129,16 @@ def barrier() -> None:
         dist.barrier(device_ids=[torch.cuda.current_device()])
 
 
+def rccl_hung() -> bool:
+    """True when this rank's RCCL probe never returned (its thread is still inside the collective): skip destroy_process_group."""
+    return bool(_STATE["rccl_hung"])
+
+
 def backend_info() -> dict:
     """What the N > 1 path runs on — for bench.py's JSON line and the fallback message."""
     info = {"backend": _STATE["backend"], "data_via_host": bool(_STATE["data_via_host"] or (_STATE["backend"] or "gloo") != "nccl"),
-            "rccl_error": _STATE["rccl_error"], "torch": torch.__version__, "hip": getattr(torch.version, "hip", None),
+            "rccl_error": _STATE["rccl_error"], "rccl_probe_first_ms": _STATE["rccl_probe_first_ms"], "rccl_probe_allreduce_ms": _STATE["rccl_probe_ms"],
+            "torch": torch.__version__, "hip": getattr(torch.version, "hip", None),
             "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
             "HSA_ENABLE_IPC_MODE_LEGACY_set_by": "ccdm" if _STATE["hsa_ipc_legacy_set_here"] else "environment"}
     try:

@@ -204,7 +204,10 @@ class SamplerEngine:
                                  skip_wide=bool(skip_src is not None and prec == hip.PREC_F16X3 and ksize == 3 and stride == 1 and not up
                                                 and wout >= 32 and hout * wout > 512 and cout <= 32
                                                 and all(t.C % 32 == 0 for t in skip_src)),
-                                 io_bytes=io, gn_read_bytes=(4 * cin * hin * win if gn is not None else 0), weight_bytes=wbytes, flop=flop))
+                                 io_bytes=io, gn_read_bytes=(4 * cin * hin * win if gn is not None else 0), weight_bytes=wbytes, flop=flop,
+                                 # bytes the launch really has to move per sample beyond SURVEY 8d's conv-io figure: the identity-residual
+                                 # read of a ResBlock's second conv (8d has no term for it; bench.py adds it to must_move, not to `achieved`)
+                                 resid_bytes=(4 * cout * hout * wout if resid is not None else 0)))
         self._fold_stats(out)
         return out
 
@@ -632,7 +635,7 @@ class SamplerEngine:
     def raise_range_error(self) -> None:
         raise hip.CcdmRangeError(
             "the network output is not finite" + (": a staged activation left the range of the fp16 split (|a| >= 4094, "
-            "include/ccdm_hip.h); re-run with prec=PREC_F32" if self.prec == hip.PREC_F16X3 else " (exact-fp32 kernels: check the weights and inputs)"))
+            "include/ccdm_hip.h); re-run with prec=PREC_F32" if self.prec != hip.PREC_F32 else " (exact-fp32 kernels: check the weights and inputs)"))
 
     def raise_if_flagged(self) -> None:
         """Synchronises with the engine's stream.  Raises CcdmRangeError (and clears the flag) if any head output of the runs

@@ -142,8 +142,8 @@ def apply_sampler_options(model, params: dict) -> None:
          rng:  "philox" (default, device RNG) | "torch_cpu" (host generator in the reference's consumption order, parity mode)
          prec: "f16x3" (default) | "f32" (exact-fp32 kernels) | "f16" (OPT-IN single-pass fast mode: operands rounded to fp16, outside
                the 1e-4 parity contract — tools/fast_mode_report.py prints its error; logged as a warning)
-         philox_seed, use_graph, substreams, on_range_error (layers | f32 | raise), f32_layers, slicing: DenoisingModel attributes of the
-         same names."""
+         philox_seed, use_graph, substreams, calibrate_mode, on_range_error (layers | f32 | raise), f32_layers, slicing: DenoisingModel
+         attributes of the same names."""
     from . import hip
     model.rng = str(params.get("rng", "philox"))
     prec = str(params.get("prec", "f16x3")).lower()
@@ -156,7 +156,8 @@ def apply_sampler_options(model, params: dict) -> None:
     model.prec = {"f32": hip.PREC_F32, "f16x3": hip.PREC_F16X3, "f16": hip.PREC_F16}[prec]
     model.philox_seed = int(params.get("philox_seed", 0))
     model.use_graph = bool(params.get("use_graph", True))
-    model.substreams = int(params.get("substreams", 0))          # 0 = automatic (DenoisingModel)
+    model.substreams = int(params.get("substreams", 0))          # 0 = automatic (DenoisingModel): the execution mode is measured once per geometry
+    model.calibrate_mode = bool(params.get("calibrate_mode", True))    # False: the static rule (two streams from 32 x 128x128 pixels) and use_graph as set
     model.on_range_error = str(params.get("on_range_error", "layers"))
     model.f32_layers = set(params.get("f32_layers", []) or [])       # conv layers pinned to fp32 up front (tools/range_report.py --pin)
     model.slicing = str(params.get("slicing", "throughput"))

@@ -196,6 +196,19 @@ class CcdmRangeError(CcdmHipError):
     split's range (|a| >= 4094, include/ccdm_hip.h).  Outputs of that run are invalid."""
 
 
+def clean_build_tree(keep: Optional[str] = None) -> None:
+    """Remove the object directories of every build flavour except `keep` and the default one (build/obj).  Never called implicitly
+    by an incremental build: another process may be compiling into one of them."""
+    import shutil
+    root = os.path.join(_HERE, "build")
+    if not os.path.isdir(root):
+        return
+    for d in os.listdir(root):
+        p = os.path.join(root, d)
+        if d.startswith("obj_") and p != keep and os.path.isdir(p):
+            shutil.rmtree(p, ignore_errors=True)
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile libccdm_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).  One object per source,
     compiled in parallel into <package>/build/ (only the sources that changed), then linked."""
@@ -213,17 +226,15 @@ def build(force: bool = False, verbose: bool = False) -> str:
     flavour = hashlib.sha1(" ".join(extra).encode()).hexdigest()[:10] if extra else "default"
     objdir = os.path.join(_HERE, "build", "obj" + ("" if flavour == "default" else "_" + flavour))
     os.makedirs(objdir, exist_ok=True)
-    # prune: objects whose source left the list, and the object directories of flavours other than this one and the default
-    # (the build tree travels to no box, but seventeen stale flavours were 36 MB of it)
-    import shutil
+    # prune: objects whose source left the list; the object directories of OTHER flavours only on force=True (clean_build_tree() does the
+    # same explicitly) — alternating ablation / experiment / default builds keep their incremental caches, and a concurrent build of
+    # another flavour (the A/B tools) never loses its directory mid-compile
     wanted = {os.path.basename(s) + ".o" for s in srcs}
     for f in os.listdir(objdir):
         if f.endswith(".o") and f not in wanted:
             os.remove(os.path.join(objdir, f))
-    for d in os.listdir(os.path.dirname(objdir)):
-        p = os.path.join(os.path.dirname(objdir), d)
-        if d.startswith("obj_") and p != objdir and os.path.isdir(p):
-            shutil.rmtree(p, ignore_errors=True)
+    if force:
+        clean_build_tree(keep=objdir)
     stamp = LIB_PATH + ".flavour"
     try:
         linked_flavour = open(stamp).read().strip()

@@ -298,6 +298,14 @@ class DenoisingModel(nn.Module):
         # kernels of the other), one below.  bench.py times this default and collects its per-kernel taps in a separate
         # single-stream pass (under concurrency a launch's duration no longer describes the kernel).
         self.substreams = 0
+        # Round 6: with substreams = 0 the choice between the bit-identical execution modes — one stream or two sub-batch streams, HIP-graph
+        # replay or eager launches — is MEASURED once per (batch geometry, weights) on the box at hand (`_calibrate_mode`: a dozen denoise
+        # steps of the call's own workload in each mode, results discarded), because the ranking moves with the box by a few per cent
+        # (round 5: two graph streams 89.7 against 85.9 samples/s on one box, 89.4 against 91.9 on another).  The samples do not depend on it.
+        # False = the static rule (auto_substreams) and `use_graph` as set.  `mode_choice` records what was measured and picked.
+        self.calibrate_mode = True
+        self.mode_choice: Dict[Any, dict] = {}
+        self.last_mode: Optional[Tuple[int, bool]] = None           # (sub-batch streams, graph replay) of the most recent sampling call
         self.prec = hip.PREC_F16X3
         # what to do when a PREC_F16X3 run reports a range overflow (hip.CcdmRangeError):
         # "layers" (default) = repeat the call with the exact-fp32 kernels (same seeds, so its samples are the ones an all-fp32 run
@@ -471,6 +479,50 @@ class DenoisingModel(nn.Module):
                     self._engines = {k: v for k, v in self._engines.items() if k[6] == hip.PREC_F32}
             return out
 
+    # ------------------------------------------------------------------ measured choice of the execution mode (substreams = 0)
+    CALIBRATION_MIN_STEPS = 100         # shorter walks are not worth a calibration (~200 denoise steps of probing): the static rule decides
+    CALIBRATION_STEPS = (4, 16)         # (untimed, timed) denoise steps per candidate mode and round
+    CALIBRATION_ROUNDS = 3              # interleaved timing rounds; the minimum counts (C2: ~0.6 s once per geometry and set of weights)
+
+    def _calibrate_mode(self, x: Tensor, condition: Tensor, feature_condition: Optional[Tensor], prepare, run_steps,
+                        nsub_rule: int, graph_allowed: bool) -> Tuple[int, bool]:
+        """Time the bit-identical execution modes on this call's own workload and return the fastest (sub-batch streams, graph replay).
+        Candidates: one stream or `nsub_rule` streams; graph replay (if `use_graph` allows it) or eager launches.  Each runs
+        CALIBRATION_ROUNDS x CALIBRATION_STEPS denoise steps from x_T with the call's tables (the draws are discarded: every engine's inputs are set again
+        by the caller, Philox counters depend on the step row only, the host generator is not touched — this path is never taken with
+        rng = "torch_cpu").  Once per (geometry, precision, slicing, weights); `mode_choice` keeps the timings."""
+        import time
+        N, K, H, W = x.shape
+        ck = (N, K, H, W, int(condition.shape[1]), None if feature_condition is None else tuple(feature_condition.shape[1:]), self.prec,
+              self._fine_slices(N), graph_allowed, nsub_rule, self._weights_key())
+        hit = self.mode_choice.get(ck)
+        if hit is not None:
+            return hit["nsub"], hit["use_graph"]
+        warm, timed = self.CALIBRATION_STEPS
+        cands = [(ns, g) for ns in (nsub_rule, 1) for g in ((True, False) if graph_allowed else (False,))]
+        parts_of = {ns: prepare(ns) for ns in (nsub_rule, 1)}
+        dev = parts_of[1][0][0].device
+        for ns, g in cands:                                                   # untimed: captures each engine's graph, warms weights and code
+            run_steps(parts_of[ns], 0, warm, [None] * ns, 0, g)
+        torch.cuda.synchronize(dev)
+        times = {c: float("inf") for c in cands}
+        for _ in range(self.CALIBRATION_ROUNDS):                              # interleaved rounds, minimum per candidate: the modes differ by 1-4 %
+            for ns, g in cands:
+                t0 = time.perf_counter()
+                run_steps(parts_of[ns], 0, timed, [None] * ns, 0, g)
+                torch.cuda.synchronize(dev)
+                times[(ns, g)] = min(times[(ns, g)], (time.perf_counter() - t0) / timed * 1e3)
+        for parts_ in parts_of.values():
+            for eng, lo, hi in parts_:
+                eng.check_and_clear_flag()                                   # (the real call reports overflows; a probe run must not leave a flag behind)
+        best = min(times, key=times.get)
+        self.mode_choice = {k_: v for k_, v in self.mode_choice.items() if k_[-1] == ck[-1]}      # (entries of older weights go)
+        self.mode_choice[ck] = {"nsub": best[0], "use_graph": best[1],
+                                "ms_per_denoise_step": {f"{ns} stream{'s' if ns > 1 else ''}, {'graph' if g else 'eager'}": round(v, 4) for (ns, g), v in times.items()}}
+        LOGGER.info("execution mode for N=%d %dx%d: %d stream(s), %s (ms per denoise step: %s)", N, H, W, best[0], "graph" if best[1] else "eager",
+                    self.mode_choice[ck]["ms_per_denoise_step"])
+        return best
+
     def forward_step(self, x: Tensor, condition: Tensor, feature_condition: Tensor, t: Tensor) -> dict:
         return self._with_range_fallback(lambda: self._forward_step(x, condition, feature_condition, t))
 
@@ -530,18 +582,37 @@ class DenoisingModel(nn.Module):
         # by the global sample index or sliced from the full-batch host draw): the results are bit-identical.
         # automatic: two sub-batches once the batch holds as many pixels as 32 LIDC samples (N >= 32 at 128x128; the Cityscapes-shaped
         # batches of 16 x 256x512 and 4 x 512x1024 qualify: +2.3 % / +2.0 % measured), one below
+        def prepare(nsub_: int):
+            bounds = [(N * j) // nsub_ for j in range(nsub_ + 1)]
+            parts_ = []
+            for j in range(nsub_):
+                lo, hi = bounds[j], bounds[j + 1]
+                fc = feature_condition[lo:hi] if feature_condition is not None else None
+                eng = self._engine(x[lo:hi], condition[lo:hi], fc, slot=j)
+                with eng.enter():
+                    eng.set_inputs(self._to_index(x[lo:hi], eng.device), condition[lo:hi].to(eng.device), fc)
+                    eng.set_tables([float(t) for t in t_values], coeffs)
+                parts_.append((eng, lo, hi))
+            return parts_
+
+        def run_steps(parts_, s0_: int, s1_: int, noises_, noise_row0_: int, graph_: bool):
+            if len(parts_) == 1:
+                parts_[0][0].run(s1_ - s0_, first_row=s0_, noise=noises_[0], noise_row0=noise_row0_, philox_seed=key,
+                                 sample_offset=self.sample_offset, use_graph=graph_)
+            else:
+                for s in range(s0_, s1_):              # one step of every sub-batch in turn: the streams advance side by side
+                    for j, (eng, lo, hi) in enumerate(parts_):
+                        eng.run(1, first_row=s, noise=noises_[j], noise_row0=noise_row0_, philox_seed=key,
+                                sample_offset=self.sample_offset + lo, use_graph=graph_)
+
         nsub = int(self.substreams) if int(self.substreams) > 0 else auto_substreams(N, H, W)
         nsub = max(1, min(nsub, N))
-        bounds = [(N * j) // nsub for j in range(nsub + 1)]
-        parts = []
-        for j in range(nsub):
-            lo, hi = bounds[j], bounds[j + 1]
-            fc = feature_condition[lo:hi] if feature_condition is not None else None
-            eng = self._engine(x[lo:hi], condition[lo:hi], fc, slot=j)
-            with eng.enter():
-                eng.set_inputs(self._to_index(x[lo:hi], eng.device), condition[lo:hi].to(eng.device), fc)
-                eng.set_tables([float(t) for t in t_values], coeffs)
-            parts.append((eng, lo, hi))
+        use_graph = bool(self.use_graph)
+        if (int(self.substreams) <= 0 and self.calibrate_mode and not host_rng and self._range_probe is None and nsub > 1
+                and S >= self.CALIBRATION_MIN_STEPS):
+            nsub, use_graph = self._calibrate_mode(x, condition, feature_condition, prepare, run_steps, nsub, use_graph)
+        self.last_mode = (nsub, use_graph)
+        parts = prepare(nsub)
         # Step blocks.  Device RNG: one block.  Host RNG (parity mode): the Exp(1) noise is drawn from torch's CPU generator
         # one [gN*H*W, K] block per sampling step — exactly the reference's consumption order, whatever the blocking — and
         # uploaded a bounded number of steps at a time, so host and device hold O(block), not O(T), noise.
@@ -563,14 +634,7 @@ class DenoisingModel(nn.Module):
                 for j, (eng, lo, hi) in enumerate(parts):
                     with torch.cuda.stream(eng.stream):
                         noises[j] = host[:, first + lo:first + hi].contiguous().to(eng.device)
-            if nsub == 1:
-                parts[0][0].run(s1 - s0, first_row=s0, noise=noises[0], noise_row0=s0, philox_seed=key,
-                                sample_offset=self.sample_offset, use_graph=self.use_graph)
-            else:
-                for s in range(s0, s1):              # one step of every sub-batch in turn: the streams advance side by side
-                    for j, (eng, lo, hi) in enumerate(parts):
-                        eng.run(1, first_row=s, noise=noises[j], noise_row0=s0, philox_seed=key,
-                                sample_offset=self.sample_offset + lo, use_graph=self.use_graph)
+            run_steps(parts, s0, s1, noises, s0, use_graph)
             self._probe_ranges([p_[0] for p_ in parts])
         outs = []
         for eng, lo, hi in parts:

@@ -2275,6 +2275,41 @@ def test_unattributable_overflow_switches_the_model_to_fp32_once(U):
     assert model.prec == hip.PREC_F16X3 and model.range_events["reset_on_new_weights"] == 1 and model.range_events["overflows"] == 1
 
 
+def test_measured_execution_mode_is_bit_neutral(U, lidc_model):
+    """substreams = 0 (the default): a sampling call long enough to pay for it measures the bit-identical execution modes once — one
+    stream or two sub-batch streams, graph replay or eager launches — and runs the fastest; the samples are those of any fixed mode,
+    the choice is recorded, and a second call does not measure again."""
+    model, _ = lidc_model
+    N = 32
+    rng = np.random.default_rng(17)
+    image = torch.from_numpy(rng.uniform(-1, 1, (N, 1, 128, 128)).astype(np.float32)).to(U.DEV)
+    x = O.one_hot_bchw(torch.from_numpy(rng.integers(0, 2, (N, 128, 128))), 2).to(U.DEV)
+    t = torch.as_tensor(10040)
+    keep = (model.rng, model.philox_seed, model.philox_advance, model.substreams, model.use_graph, model.calibrate_mode, model.step_T_sample)
+    model.CALIBRATION_MIN_STEPS, model.CALIBRATION_STEPS, model.CALIBRATION_ROUNDS = 40, (2, 6), 2        # (instance overrides: a short probe)
+    try:
+        model.rng, model.philox_seed, model.philox_advance, model.step_T_sample = "philox", 5, False, "confidence"
+        model.substreams, model.use_graph, model.calibrate_mode, model.mode_choice = 0, True, True, {}
+        a = model(x, image, t=t)["diffusion_out"].clone()
+        assert len(model.mode_choice) == 1
+        choice = next(iter(model.mode_choice.values()))
+        assert len(choice["ms_per_denoise_step"]) == 4 and model.last_mode == (choice["nsub"], choice["use_graph"])
+        print("measured modes:", choice)
+        b = model(x, image, t=t)["diffusion_out"].clone()
+        assert len(model.mode_choice) == 1 and torch.equal(a, b)
+        for sub, graph in ((1, False), (2, True)):
+            model.substreams, model.use_graph, model.calibrate_mode = sub, graph, False
+            c = model(x, image, t=t)["diffusion_out"]
+            assert model.last_mode == (sub, graph) and torch.equal(a, c), (sub, graph)
+        # a walk too short to pay for a measurement takes the static rule
+        model.substreams, model.use_graph, model.calibrate_mode, model.mode_choice = 0, True, True, {}
+        model(x, image, t=torch.as_tensor(10004))
+        assert model.mode_choice == {} and model.last_mode == (2, True)
+    finally:
+        (model.rng, model.philox_seed, model.philox_advance, model.substreams, model.use_graph, model.calibrate_mode, model.step_T_sample) = keep
+        del model.CALIBRATION_MIN_STEPS, model.CALIBRATION_STEPS, model.CALIBRATION_ROUNDS
+
+
 def test_graph_survives_a_new_philox_key_and_new_noise_blocks(U):
     """The per-run epilogue fields live in a device block (ccdm_post_run): successive sampling calls (a new Philox key each) and the
     several host-noise blocks of one call replay ONE captured graph per engine instead of destroying and re-capturing it."""
@@ -2489,7 +2524,12 @@ def test_bench_two_ranks_is_the_command_the_driver_runs(U, tmp_path):
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
         return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
 
-    two = run(["--gpus", "2"])
+    two = run(["--gpus", "2", "--ref-value", "10.0"])
+    assert "roofline_shapes" not in two and "per_stage_us" not in two and "secondary_note" in two      # N > 1: rank 0's untimed extras are opt-in (--secondary)
+    assert abs(two["weak_scaling_efficiency"] - two["value"] / 20.0) < 1e-9
+    assert all(p["ms_per_denoise_step"] > 0 and p["samples_per_s"] > 0 for p in two["per_rank"]) and two["slowest_rank"] in (0, 1)
+    assert "rccl_probe_first_ms" in two["distributed"] and 0 <= two["gather_share_of_pass"] <= 1
+    two = run(["--gpus", "2", "--secondary"])
     assert two["n_gpus"] == 2 and two["config"]["global_batch"] == 12 and two["scaling"] == "weak"
     assert np.isfinite(two["value"]) and two["value"] > 0 and abs(two["value"] - 12 / (two["ms_per_step"] * 1e-3)) < 1e-6 * two["value"]
     pr = two["per_rank"]

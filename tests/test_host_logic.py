@@ -450,7 +450,7 @@ def test_bench_self_launch_command(monkeypatch):
     """`python bench.py --gpus N` without a launcher environment starts its own ranks with torch.distributed.run."""
     import bench
     seen = {}
-    monkeypatch.setattr(bench.subprocess, "call", lambda cmd, env=None: seen.update(cmd=cmd, env=env) or 0)
+    monkeypatch.setattr(bench, "_run_ranks", lambda cmd, env=None: (seen.update(cmd=cmd, env=env) or 0, ""))
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2", "--warmup", "1"])
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         monkeypatch.delenv(k, raising=False)
@@ -464,22 +464,23 @@ def test_bench_self_launch_command(monkeypatch):
 
 
 def test_bench_self_launch_retries_once_without_its_own_ipc_override(monkeypatch):
-    """Where bench.py itself had to set HSA_ENABLE_IPC_MODE_LEGACY=0 and the N-rank job fails, it is started once more without the
-    override; an override that came from the environment is never removed."""
+    """Where bench.py itself had to set HSA_ENABLE_IPC_MODE_LEGACY=0 and the N-rank job fails WITH AN IPC / RCCL ERROR, it is started
+    once more without the override; an override that came from the environment is never removed, and any other failure is not retried."""
     import bench
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         monkeypatch.delenv(k, raising=False)
-    for preset, want in ((None, ["0", None]), ("0", ["0"])):
+    for preset, stderr, want in ((None, "hipIpcGetMemHandle: invalid argument", ["0", None]), ("0", "hipIpcGetMemHandle: invalid argument", ["0"]),
+                                 (None, "AssertionError: something else", ["0"])):
         envs = []
-        monkeypatch.setattr(bench.subprocess, "call", lambda cmd, env=None: envs.append(env.get("HSA_ENABLE_IPC_MODE_LEGACY")) or 7)
+        monkeypatch.setattr(bench, "_run_ranks", lambda cmd, env=None, stderr=stderr: (envs.append(env.get("HSA_ENABLE_IPC_MODE_LEGACY")) or 7, stderr))
         if preset is None:
             monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY", raising=False)
         else:
             monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", preset)
         with pytest.raises(SystemExit) as e:
             bench.main()
-        assert e.value.code == 7 and envs == want, (preset, envs)
+        assert e.value.code == 7 and envs == want, (preset, stderr, envs)
 
 
 def test_host_noise_is_drawn_in_bounded_blocks(monkeypatch):
