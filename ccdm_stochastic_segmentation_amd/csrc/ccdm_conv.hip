@@ -1115,7 +1115,10 @@ static int conv_slices_default(int tiles, bool up2, int stride) {
     if (!up2 && tiles >= 24 && tiles < 48) return tiles < 32 ? tiles : 32;
     if (tiles >= 128) return tiles / 16 * 3;
     if (tiles >= 48) return 12;
-    if (tiles >= 16) return 8;       // 64x64: 8 slices x 2 tiles (512 blocks, all resident) 28.8 us vs 16 x 1 (1024 blocks, a thin second round) 30.7
+    // 64x64: 8 slices x 2 tiles (512 blocks, all resident) 28.8 us vs 16 x 1 (1024 blocks, a thin second round) 30.7.  Round 6, same-box
+    // A/B of 12 / 16 slices here and 16 / 24 at 128x128 (profiles/r06_slices_ab.txt): the two-stream mode gains 0-1.7 % from more, shorter
+    // blocks (its half batches leave slots empty), the single-stream mode loses 0.3-2.5 % — inside the box spread either way; not adopted.
+    if (tiles >= 16) return 8;
     return tiles < 16 ? tiles : 16;
 }
 
