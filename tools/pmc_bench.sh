@@ -16,6 +16,7 @@ run() { # name counters...
 }
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU
 run sq2 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_SALU
+run sq3 SQ_LDS_IDX_ACTIVE
 run tcc1 FETCH_SIZE
 run tcc2 WRITE_SIZE
 run grbm GRBM_GUI_ACTIVE GRBM_COUNT

@@ -40,6 +40,12 @@ for key, cs in agg.items():
         e["mfma_busy"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (m["GRBM_GUI_ACTIVE"] / 8 * 1024)
     if "SQ_ACTIVE_INST_VALU" in m and "GRBM_GUI_ACTIVE" in m and m["GRBM_GUI_ACTIVE"] > 0:
         e["valu_active"] = 4 * m["SQ_ACTIVE_INST_VALU"] / (m["GRBM_GUI_ACTIVE"] / 8 * 1024)       # quad-cycles -> cycles
+    if m.get("SQ_LDS_IDX_ACTIVE", 0) > 0 and "SQ_LDS_BANK_CONFLICT" in m:
+        # MI355X_MICROARCH.md §LDS: SQ_LDS_BANK_CONFLICT = extra LDS-array cycles, SQ_LDS_IDX_ACTIVE = all LDS-array cycles
+        e["lds_conflict_share_of_lds_cycles"] = m["SQ_LDS_BANK_CONFLICT"] / m["SQ_LDS_IDX_ACTIVE"]
+        if m.get("GRBM_GUI_ACTIVE", 0) > 0:
+            e["lds_busy"] = m["SQ_LDS_IDX_ACTIVE"] / (m["GRBM_GUI_ACTIVE"] / 8 * 256)          # one LDS per CU: 256 of them
+            e["lds_conflict_share_of_kernel_time"] = m["SQ_LDS_BANK_CONFLICT"] / (m["GRBM_GUI_ACTIVE"] / 8 * 256)
     if "SQ_WAVE_CYCLES" in m and m["SQ_WAVE_CYCLES"] > 0:
         wc = m["SQ_WAVE_CYCLES"]
         e["wave_time_split"] = {"valu_active": m.get("SQ_ACTIVE_INST_VALU", 0) / wc, "lds_active": m.get("SQ_ACTIVE_INST_LDS", 0) / wc,
