@@ -483,6 +483,58 @@ def test_bench_self_launch_retries_once_without_its_own_ipc_override(monkeypatch
         assert e.value.code == 7 and envs == want, (preset, stderr, envs)
 
 
+def test_execution_mode_is_measured_once_and_only_where_it_pays(monkeypatch):
+    """substreams = 0 (host logic on a stub engine whose run() sleeps by mode): a sampling call of >= CALIBRATION_MIN_STEPS steps on a
+    batch the static rule gives two streams times {2, 1 streams} x {graph, eager}, keeps the fastest, re-sets every engine's inputs
+    for the real walk, and does not measure again for the same geometry and weights; short walks, small batches, explicit
+    `substreams`, `calibrate_mode = False` and the host-noise parity mode take the static rule without measuring."""
+    import time
+    from ccdm_stochastic_segmentation_amd import models as Mo
+    m = lidc_model().eval()
+    log = []
+
+    class Eng:
+        device = torch.device("cpu"); stream = None
+        def __init__(self, n): self.N = n; self.xt = torch.zeros(n, 128 * 128, dtype=torch.uint8); self.out_probs = torch.zeros(n, 128, 128, 2)
+        def enter(self):
+            import contextlib; return contextlib.nullcontext()
+        def leave(self): pass
+        def set_inputs(self, *a): log.append(("inputs", self.N))
+        def set_tables(self, *a): pass
+        def raise_if_flagged(self): pass
+        def check_and_clear_flag(self): return False
+        def run(self, n_steps, *, first_row, use_graph, **kw):
+            log.append(("run", self.N, n_steps, first_row, use_graph))
+            # one stream eager is the fastest "mode" of this stub: everything else pays 0.3 ms per step and engine
+            time.sleep(n_steps * (1e-5 if (self.N == 32 and not use_graph) else 3e-4))
+    engines = {}
+    monkeypatch.setattr(Mo.DenoisingModel, "_engine", lambda self, x, c, f, slot=0: engines.setdefault((x.shape[0], slot), Eng(x.shape[0])))
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    monkeypatch.setattr(torch.cuda, "stream", lambda s: __import__("contextlib").nullcontext())
+    m.CALIBRATION_MIN_STEPS, m.CALIBRATION_STEPS, m.CALIBRATION_ROUNDS = 20, (1, 2), 2
+    x = torch.zeros(32, 2, 128, 128); x[:, 0] = 1
+    cond = torch.zeros(32, 1, 128, 128)
+    m._forward_denoising(x, cond, None, init_t=10020)
+    assert len(m.mode_choice) == 1 and m.last_mode == (1, False)
+    choice = next(iter(m.mode_choice.values()))
+    assert set(choice["ms_per_denoise_step"]) == {"2 streams, graph", "2 streams, eager", "1 stream, graph", "1 stream, eager"}
+    # the real walk: inputs set again after the probes, then ONE run of all 20 steps on the chosen (single, eager) engine
+    last_inputs = max(i for i, e in enumerate(log) if e[0] == "inputs")
+    assert log[last_inputs] == ("inputs", 32) and log[last_inputs + 1:] == [("run", 32, 20, 0, False)]
+    n_probe = len(log)
+    log.clear()
+    m._forward_denoising(x, cond, None, init_t=10020)                         # same geometry and weights: no second measurement
+    assert [e for e in log if e[0] == "run"] == [("run", 32, 20, 0, False)] and len(log) < n_probe
+    # no measurement: short walk | small batch | explicit substreams | calibrate_mode off | host-noise parity mode
+    for kw, xs, init_t, want in (({}, x, 10004, (2, True)), ({}, x[:8], 10020, (1, True)), ({"substreams": 2}, x, 10020, (2, True)),
+                                 ({"calibrate_mode": False}, x, 10020, (2, True)), ({"rng": "torch_cpu"}, x, 10020, (2, True))):
+        m.mode_choice, m.substreams, m.calibrate_mode, m.rng = {}, 0, True, "philox"
+        for k_, v in kw.items():
+            setattr(m, k_, v)
+        m._forward_denoising(xs, cond[:xs.shape[0]], None, init_t=init_t)
+        assert m.mode_choice == {} and m.last_mode == want, (kw, init_t, m.last_mode)
+
+
 def test_host_noise_is_drawn_in_bounded_blocks(monkeypatch):
     """rng='torch_cpu': the per-step Exp(1) draws are consumed from torch's generator in the reference's order whatever the block
     size, and no more than one block is resident (checked on the host logic with a stub engine)."""
