@@ -417,7 +417,8 @@ def main():
         mine = torch.tensor([dt, t_gather[0]], dtype=torch.float64)
         allr = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
-        text = json.dumps({"device": torch.cuda.get_device_name(dev), "cuda_device": int(dev.index), "out_sha256": digest}).encode()[:384]
+        text = json.dumps({"device": torch.cuda.get_device_name(dev), "cuda_device": int(dev.index), "out_sha256": digest,
+                           "mode": f"{nsub} stream{'s' if nsub > 1 else ''}, {'graph' if use_graph else 'eager'}"}).encode()[:384]
         blob = torch.zeros(384, dtype=torch.uint8)
         blob[:len(text)] = torch.frombuffer(bytearray(text), dtype=torch.uint8)
         blobs = [torch.empty_like(blob) for _ in range(world)]
