@@ -21,7 +21,8 @@ def reflow(text: str, width: int = 118) -> str:
     for line in text.split("\n"):
         if line.strip().startswith("```"):
             flush(); in_code = not in_code; out.append(line); continue
-        if in_code or line.lstrip().startswith("|") or line.startswith("#") or not line.strip():
+        is_table = line.lstrip().startswith("|") and line.rstrip().endswith("|") and line.count("|") >= 3
+        if in_code or is_table or line.startswith("#") or not line.strip():
             flush(); out.append(line); continue
         m = re.match(r"^(\s*)([-*+]|\d+\.)\s+", line)
         if m:                                                   # a new list item
