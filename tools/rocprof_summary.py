@@ -16,7 +16,7 @@ def rows_from_db(path):
 
 
 def rows_from_csv(path):
-    agg = defaultdict(lambda: dict(n=0, tot=0, mn=1 << 62, mx=0))
+    agg = defaultdict(lambda: dict(n=0, tot=0, mn=1 << 62, mx=0, all=[]))
     with open(path) as f:
         for r in csv.DictReader(f):
             d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
@@ -24,7 +24,7 @@ def rows_from_csv(path):
             key = (r["Kernel_Name"], f'{int(r.get("Grid_Size_X", r.get("Grid_Size", 0))) // max(wg, 1)}x{r.get("Grid_Size_Y", 1)}', wg,
                    r.get("LDS_Block_Size", ""), r.get("VGPR_Count", ""))
             a = agg[key]
-            a["n"] += 1; a["tot"] += d; a["mn"] = min(a["mn"], d); a["mx"] = max(a["mx"], d)
+            a["n"] += 1; a["tot"] += d; a["mn"] = min(a["mn"], d); a["mx"] = max(a["mx"], d); a["all"].append(d)
     out = [dict(name=k[0], grid=k[1], wg=k[2], lds=k[3], vgpr=k[4], **v) for k, v in agg.items()]
     return sorted(out, key=lambda r: -r["tot"])
 
@@ -60,10 +60,15 @@ def main():
     total = sum(r["tot"] for r in rows)
     lines = [f"# rocprofv3 --kernel-trace summary of {path.split('/')[-1]}", "",
              f"total kernel time {total / 1e6:.2f} ms over {sum(r['n'] for r in rows)} launches", "",
-             "| kernel | grid (blocks) | wg | LDS B | VGPR | launches | total ms | % | mean us | min us | max us |", "|---|---|---|---|---|---|---|---|---|---|---|"]
+             "`mean w/o max` drops each row's single longest launch (the first launch of a kernel pays its code load: up to 20 ms) — the figure to "
+             "compare with bench.py's HIP-event taps.", "",
+             "| kernel | grid (blocks) | wg | LDS B | VGPR | launches | total ms | % | mean us | mean w/o max | median us | min us | max us |",
+             "|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
     for r in rows[:40]:
         lines.append(f"| `{r['name'][:90]}` | {r['grid']} | {r['wg']} | {r['lds']} | {r['vgpr']} | {r['n']} | {r['tot'] / 1e6:.2f} | "
-                     f"{100 * r['tot'] / total:.1f} | {r['tot'] / r['n'] / 1e3:.1f} | {r['mn'] / 1e3:.1f} | {r['mx'] / 1e3:.1f} |")
+                     f"{100 * r['tot'] / total:.1f} | {r['tot'] / r['n'] / 1e3:.1f} | "
+                     f"{((r['tot'] - r['mx']) / max(r['n'] - 1, 1) / 1e3):.1f} | "
+                     f"{(sorted(r['all'])[len(r['all']) // 2] / 1e3 if r.get('all') else float('nan')):.1f} | {r['mn'] / 1e3:.1f} | {r['mx'] / 1e3:.1f} |")
     if not path.endswith(".db"):
         ops = per_op_table(path)
         if ops:
