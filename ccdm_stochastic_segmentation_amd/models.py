@@ -485,7 +485,7 @@ class DenoisingModel(nn.Module):
     CALIBRATION_ROUNDS = 3              # interleaved timing rounds; the minimum counts (C2: ~0.6 s once per geometry and set of weights)
 
     def _calibrate_mode(self, x: Tensor, condition: Tensor, feature_condition: Optional[Tensor], prepare, run_steps,
-                        nsub_rule: int, graph_allowed: bool) -> Tuple[int, bool]:
+                        nsub_rule: int, graph_allowed: bool, n_rows: int) -> Tuple[int, bool]:
         """Time the bit-identical execution modes on this call's own workload and return the fastest (sub-batch streams, graph replay).
         Candidates: one stream or `nsub_rule` streams; graph replay (if `use_graph` allows it) or eager launches.  Each runs
         CALIBRATION_ROUNDS x CALIBRATION_STEPS denoise steps from x_T with the call's tables (the draws are discarded: every engine's inputs are set again
@@ -498,9 +498,16 @@ class DenoisingModel(nn.Module):
         hit = self.mode_choice.get(ck)
         if hit is not None:
             return hit["nsub"], hit["use_graph"]
-        warm, timed = self.CALIBRATION_STEPS
+        warm, timed = (max(1, min(int(v), n_rows)) for v in self.CALIBRATION_STEPS)       # (rows of the call's own tables)
         cands = [(ns, g) for ns in (nsub_rule, 1) for g in ((True, False) if graph_allowed else (False,))]
-        parts_of = {ns: prepare(ns) for ns in (nsub_rule, 1)}
+        try:
+            parts_of = {ns: prepare(ns) for ns in (nsub_rule, 1)}       # (both engine sets exist from here on: twice the activation memory)
+        except torch.cuda.OutOfMemoryError:
+            LOGGER.warning("execution-mode measurement skipped for N=%d %dx%d: no memory for both engine sets; static rule (%d streams)", N, H, W, nsub_rule)
+            self._engines = {}
+            torch.cuda.empty_cache()
+            self.mode_choice[ck] = {"nsub": nsub_rule, "use_graph": graph_allowed, "ms_per_denoise_step": {}}
+            return nsub_rule, graph_allowed
         dev = parts_of[1][0][0].device
         for ns, g in cands:                                                   # untimed: captures each engine's graph, warms weights and code
             run_steps(parts_of[ns], 0, warm, [None] * ns, 0, g)
@@ -610,7 +617,7 @@ class DenoisingModel(nn.Module):
         use_graph = bool(self.use_graph)
         if (int(self.substreams) <= 0 and self.calibrate_mode and not host_rng and self._range_probe is None and nsub > 1
                 and S >= self.CALIBRATION_MIN_STEPS):
-            nsub, use_graph = self._calibrate_mode(x, condition, feature_condition, prepare, run_steps, nsub, use_graph)
+            nsub, use_graph = self._calibrate_mode(x, condition, feature_condition, prepare, run_steps, nsub, use_graph, S)
         self.last_mode = (nsub, use_graph)
         parts = prepare(nsub)
         # Step blocks.  Device RNG: one block.  Host RNG (parity mode): the Exp(1) noise is drawn from torch's CPU generator
